@@ -1,0 +1,208 @@
+"""ctypes/NumPy binding of the CPU ORACLE (oracle/ow_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under godotoceanwaves_amd/ does (tests/test_layout.py greps for that).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class SpectrumPC(C.Structure):
+    """push-constant block of spectrum_compute.glsl:18-30"""
+    _fields_ = [("seed", C.c_int32 * 2), ("tile_length", C.c_float * 2), ("alpha", C.c_float),
+                ("peak_frequency", C.c_float), ("wind_speed", C.c_float), ("angle", C.c_float),
+                ("depth", C.c_float), ("swell", C.c_float), ("detail", C.c_float), ("spread", C.c_float)]
+
+
+class CascadeParams(C.Structure):
+    """wave_cascade_parameters.gd:7-42"""
+    _fields_ = [("tile_length", C.c_float * 2), ("displacement_scale", C.c_float), ("normal_scale", C.c_float),
+                ("wind_speed", C.c_float), ("wind_direction", C.c_float), ("fetch_length", C.c_float),
+                ("swell", C.c_float), ("spread", C.c_float), ("detail", C.c_float), ("whitecap", C.c_float),
+                ("foam_amount", C.c_float), ("spectrum_seed", C.c_int32 * 2),
+                ("should_generate_spectrum", C.c_int32), ("time", C.c_double),
+                ("foam_grow_rate", C.c_double), ("foam_decay_rate", C.c_double)]
+
+
+def build(native=False):
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    return os.path.join(_HERE, target)
+
+
+_libs = {}
+
+
+def lib(native=False):
+    if native in _libs:
+        return _libs[native]
+    path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    src = os.path.join(_HERE, "ow_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build(native)
+    L = C.CDLL(path)
+    f32p, u16p = np.ctypeslib.ndpointer(np.float32, flags="C"), np.ctypeslib.ndpointer(np.uint16, flags="C")
+    L.owo_jonswap_alpha.restype = C.c_double
+    L.owo_jonswap_alpha.argtypes = [C.c_double, C.c_double]
+    L.owo_jonswap_peak_angular_frequency.restype = C.c_double
+    L.owo_jonswap_peak_angular_frequency.argtypes = [C.c_double, C.c_double]
+    L.owo_hash.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+    L.owo_gaussian.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.owo_f32_to_f16.restype = C.c_uint16
+    L.owo_f32_to_f16.argtypes = [C.c_float]
+    L.owo_f16_to_f32.restype = C.c_float
+    L.owo_f16_to_f32.argtypes = [C.c_uint16]
+    L.owo_spectrum_compute.argtypes = [C.c_int, C.POINTER(SpectrumPC), f32p]
+    L.owo_omega.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p]
+    L.owo_spectrum_modulate.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, f32p, f32p]
+    L.owo_fft_butterfly.argtypes = [C.c_int, f32p]
+    L.owo_fft_rows.argtypes = [C.c_int, f32p, f32p, f32p]
+    L.owo_transpose.argtypes = [C.c_int, f32p, f32p]
+    L.owo_ifft2.argtypes = [C.c_int, f32p, f32p, f32p]
+    L.owo_unpack.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, u16p, u16p, C.c_void_p]
+    L.owo_generator_create.restype = C.c_void_p
+    L.owo_generator_create.argtypes = [C.c_int, C.c_int, C.c_float]
+    L.owo_generator_destroy.argtypes = [C.c_void_p]
+    L.owo_generator_update_cascade.argtypes = [C.c_void_p, C.c_int, C.POINTER(CascadeParams)]
+    L.owo_generator_advance.argtypes = [C.POINTER(CascadeParams), C.c_int, C.c_double]
+    for name, typ in (("spectrum", C.c_float), ("fft_half1", C.c_float), ("displacement", C.c_uint16),
+                      ("normal", C.c_uint16), ("f32", C.c_float)):
+        fn = getattr(L, "owo_generator_" + name)
+        fn.restype = C.POINTER(typ)
+        fn.argtypes = [C.c_void_p, C.c_int]
+    L.owo_generator_set_normal.argtypes = [C.c_void_p, C.c_int, u16p]
+    L.owo_num_threads.restype = C.c_int
+    _libs[native] = L
+    return L
+
+
+# ---- convenience wrappers (NumPy in / NumPy out) ----------------------------------------------
+
+def jonswap_alpha(U, F_m):
+    return lib().owo_jonswap_alpha(U, F_m)
+
+
+def jonswap_peak(U, F_m):
+    return lib().owo_jonswap_peak_angular_frequency(U, F_m)
+
+
+def hash2(x, y):
+    out = (C.c_float * 2)()
+    lib().owo_hash(x & 0xFFFFFFFF, y & 0xFFFFFFFF, out)
+    return float(out[0]), float(out[1])
+
+
+def f32_to_f16_bits(a):
+    L = lib()
+    a = np.asarray(a, np.float32)
+    return np.array([L.owo_f32_to_f16(float(v)) for v in a.ravel()], np.uint16).reshape(a.shape)
+
+
+def make_pc(seed, tile, alpha, peak, wind_speed, angle, depth, swell, detail, spread):
+    pc = SpectrumPC()
+    pc.seed[0], pc.seed[1] = int(seed[0]), int(seed[1])
+    pc.tile_length[0], pc.tile_length[1] = float(tile[0]), float(tile[1])
+    pc.alpha, pc.peak_frequency, pc.wind_speed, pc.angle = alpha, peak, wind_speed, angle
+    pc.depth, pc.swell, pc.detail, pc.spread = depth, swell, detail, spread
+    return pc
+
+
+def spectrum_compute(n, pc):
+    out = np.zeros((n, n, 4), np.float32)
+    lib().owo_spectrum_compute(n, C.byref(pc), out)
+    return out
+
+
+def omega(n, tile, depth):
+    out = np.zeros((n, n), np.float32)
+    lib().owo_omega(n, tile[0], tile[1], depth, out)
+    return out
+
+
+def spectrum_modulate(n, tile, depth, time, spectrum):
+    out = np.zeros((4, n, n, 2), np.float32)
+    lib().owo_spectrum_modulate(n, tile[0], tile[1], depth, time, np.ascontiguousarray(spectrum, np.float32), out)
+    return out
+
+
+def fft_butterfly(n):
+    out = np.zeros((int(np.log2(n)), n, 4), np.float32)
+    lib().owo_fft_butterfly(n, out)
+    return out
+
+
+def fft_rows(n, table, x):
+    out = np.zeros((4, n, n, 2), np.float32)
+    lib().owo_fft_rows(n, table, np.ascontiguousarray(x, np.float32), out)
+    return out
+
+
+def ifft2(n, table, x):
+    half0 = np.ascontiguousarray(x, np.float32).copy()
+    half1 = np.zeros_like(half0)
+    lib().owo_ifft2(n, table, half0, half1)
+    return half1
+
+
+def unpack(n, fft, whitecap, grow, decay, normal_prev=None):
+    disp = np.zeros((n, n, 4), np.uint16)
+    normal = np.zeros((n, n, 4), np.uint16) if normal_prev is None else np.ascontiguousarray(normal_prev, np.uint16).copy()
+    f32 = np.zeros((n, n, 8), np.float32)
+    lib().owo_unpack(n, np.ascontiguousarray(fft, np.float32), whitecap, grow, decay, disp, normal, f32.ctypes.data)
+    return disp, normal, f32
+
+
+class Generator:
+    """WaveGenerator restatement (wave_generator.gd:17-109) on the CPU."""
+
+    def __init__(self, map_size, num_cascades, depth=20.0, native=False):
+        self.L = lib(native)
+        self.n, self.c = map_size, num_cascades
+        self.h = self.L.owo_generator_create(map_size, num_cascades, depth)
+        self.params = (CascadeParams * num_cascades)()
+
+    def close(self):
+        if self.h:
+            self.L.owo_generator_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def advance(self, delta):
+        self.L.owo_generator_advance(self.params, self.c, delta)
+
+    def update_cascade(self, i):
+        self.L.owo_generator_update_cascade(self.h, i, C.byref(self.params[i]))
+
+    def update_all(self, delta):
+        """bench mode: update() then drain every cascade (highest index first, wave_generator.gd:56-63)"""
+        self.advance(delta)
+        for i in reversed(range(self.c)):
+            self.update_cascade(i)
+
+    def _arr(self, name, i, shape, dtype):
+        p = getattr(self.L, "owo_generator_" + name)(self.h, i)
+        return np.ctypeslib.as_array(p, shape=shape).view(dtype).copy()
+
+    def spectrum(self, i):
+        return self._arr("spectrum", i, (self.n, self.n, 4), np.float32)
+
+    def fft_half1(self, i):
+        return self._arr("fft_half1", i, (4, self.n, self.n, 2), np.float32)
+
+    def displacement(self, i):
+        return self._arr("displacement", i, (self.n, self.n, 4), np.uint16)
+
+    def normal(self, i):
+        return self._arr("normal", i, (self.n, self.n, 4), np.uint16)
+
+    def f32(self, i):
+        return self._arr("f32", i, (self.n, self.n, 8), np.float32)
+
+    def set_normal(self, i, normal):
+        self.L.owo_generator_set_normal(self.h, i, np.ascontiguousarray(normal, np.uint16))
