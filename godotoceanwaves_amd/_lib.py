@@ -1,0 +1,83 @@
+"""ctypes binding of include/ocean_waves.h (libocean_waves.so).  Fails loudly: no fallback of any kind."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocean_waves.so")
+
+OW_MAX_CASCADES = 8
+OW_FLAG_DEBUG_F32 = 1
+OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
+
+
+class OceanWavesError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"ocean_waves status {status}: {message}")
+        self.status = status
+
+
+class ow_cascade_params(C.Structure):
+    """struct ow_cascade_params (WaveCascadeParameters, wave_cascade_parameters.gd:7-42)"""
+    _fields_ = [("tile_length", C.c_float * 2), ("displacement_scale", C.c_float), ("normal_scale", C.c_float),
+                ("wind_speed", C.c_float), ("wind_direction", C.c_float), ("fetch_length", C.c_float),
+                ("swell", C.c_float), ("spread", C.c_float), ("detail", C.c_float), ("whitecap", C.c_float),
+                ("foam_amount", C.c_float), ("spectrum_seed", C.c_int32 * 2),
+                ("should_generate_spectrum", C.c_int32), ("reserved", C.c_int32), ("time", C.c_double),
+                ("foam_grow_rate", C.c_double), ("foam_decay_rate", C.c_double)]
+
+
+class ow_config(C.Structure):
+    _fields_ = [("map_size", C.c_int32), ("num_cascades", C.c_int32), ("device_id", C.c_int32), ("depth", C.c_float),
+                ("stream", C.c_void_p), ("displacement_map", C.c_void_p), ("normal_map", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+# every symbol include/ocean_waves.h declares: (restype, argtypes)
+_P = C.POINTER
+SIGNATURES = {
+    "ow_create": (C.c_int, [_P(ow_config), _P(C.c_void_p)]),
+    "ow_destroy": (None, [C.c_void_p]),
+    "ow_cascade_params_default": (None, [_P(ow_cascade_params)]),
+    "ow_update": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
+    "ow_process": (C.c_int, [C.c_void_p]),
+    "ow_update_all": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
+    "ow_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),
+    "ow_cascades_remaining": (C.c_int32, [C.c_void_p]),
+    "ow_sync": (C.c_int, [C.c_void_p]),
+    "ow_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
+    "ow_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ow_set_normal_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ow_get_maps_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ow_get_spectrum": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ow_get_intermediate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ow_jonswap_alpha": (C.c_double, [C.c_double, C.c_double]),
+    "ow_jonswap_peak_angular_frequency": (C.c_double, [C.c_double, C.c_double]),
+    "ow_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ow_timing_read": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_int32), C.c_int32]),
+    "ow_last_error": (C.c_char_p, []),
+    "ow_abi_version": (C.c_int32, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libocean_waves.so (built in-tree by godotoceanwaves_amd.build).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OceanWavesError(-1, f"{LIB_PATH} is missing: run `python -m godotoceanwaves_amd.build` "
+                                  "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OW_OK:
+        raise OceanWavesError(status, load().ow_last_error().decode("utf-8", "replace"))

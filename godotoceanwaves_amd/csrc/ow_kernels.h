@@ -1,0 +1,24 @@
+// ow_kernels.h -- internal launcher interface between the host runtime and the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ow_device.h"
+
+namespace ow {
+
+struct DeviceBuffers {
+    f32x4 *h0;      // [layers][N][N] float4   (the `spectrum` texture, wave_generator.gd:31)
+    float *omega;   // [layers][N][N]          FP32 dispersion plane
+    cplx *T;        // [layers][N x'][N y][4]  transposed intermediate after the first row pass
+    u16x4 *disp;    // [layers][N][N] RGBA16F
+    u16x4 *norm;    // [layers][N][N] RGBA16F (foam in .a)
+    float *f32;     // [layers][N][N][8] or nullptr
+    const cplx *tw; // twiddle table (plan_tw_total(N) entries)
+};
+
+bool supported_map_size(int n);
+hipError_t launch_spectrum(int n, int cascade, const SpectrumPC &pc, const DeviceBuffers &buf, hipStream_t s);
+hipError_t launch_pass1(int n, int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s);
+hipError_t launch_pass2(int n, int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s);
+
+}  // namespace ow

@@ -1,0 +1,439 @@
+// ow_runtime.hip -- host runtime behind include/ocean_waves.h: the WaveGenerator of
+// assets/water/wave_generator.gd re-expressed as a HIP stream program.
+//
+//   init_gpu (:17-54)  -> ow_create : one allocation per resource for all array layers
+//   update   (:90-109) -> ow_update : flush leftovers, advance time / foam rates, arm cascades
+//   _process (:56-63)  -> ow_process: one armed cascade, highest index first
+//   _update  (:65-85)  -> enqueue() : [spectrum kernel if dirty] + pass-1 + pass-2 for a batch of cascades
+//
+// The reference issues six dispatches per cascade; here a batch of cascades is two launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ocean_waves.h"
+#include "ow_kernels.h"
+#include "ow_tables.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+ow_status fail(ow_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+
+#define OW_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(OW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr double kHostG = 9.81;  // wave_generator.gd:5
+
+}  // namespace
+
+struct ow_context {
+    int n = 0, cascades = 0, layers = 0, device = 0;
+    float depth = 20.0f;
+    hipStream_t stream = nullptr;
+    bool own_stream = false, own_disp = false, own_norm = false;
+    ow::DeviceBuffers buf{};
+    ow::cplx *tw_dev = nullptr;
+    // generator state per invocation of update() (wave_generator.gd:13-15)
+    ow_cascade_params *pass_parameters = nullptr;
+    int pass_num_cascades_remaining = 0;
+    // timing: a pool of event triples so that timed ticks stay enqueued back to back
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // 3 per timed batch: before pass 1, between, after pass 2
+    size_t ev_used = 0;
+    double t1_ms = 0, t2_ms = 0;
+    int t_launches = 0;
+};
+
+namespace {
+
+size_t plane(const ow_context *c) { return (size_t)c->n * c->n; }
+
+constexpr size_t kMaxTimedBatches = 4096;
+
+ow_status collect_timing(ow_context *c) {
+    if (c->ev_used == 0) return OW_OK;
+    OW_HIP(hipEventSynchronize(c->ev[c->ev_used - 1]));
+    for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
+        float a = 0, b = 0;
+        OW_HIP(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
+        OW_HIP(hipEventElapsedTime(&b, c->ev[i + 1], c->ev[i + 2]));
+        c->t1_ms += a;
+        c->t2_ms += b;
+        c->t_launches += 1;
+    }
+    c->ev_used = 0;
+    return OW_OK;
+}
+
+ow_status next_events(ow_context *c, hipEvent_t **out) {
+    if (c->ev_used + 3 > 3 * kMaxTimedBatches) {
+        ow_status st = collect_timing(c);
+        if (st != OW_OK) return st;
+    }
+    while (c->ev.size() < c->ev_used + 3) {
+        hipEvent_t e;
+        OW_HIP(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    *out = &c->ev[c->ev_used];
+    c->ev_used += 3;
+    return OW_OK;
+}
+
+// _update() for a batch of cascade indices (wave_generator.gd:65-85)
+ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
+    if (count <= 0) return OW_OK;
+    ow::FrameArgs args;
+    std::memset(&args, 0, sizeof(args));
+    for (int i = 0; i < count; ++i) {
+        ow_cascade_params &p = params[idx[i]];
+        if (!(p.tile_length[0] > 0.0f) || !(p.tile_length[1] > 0.0f))
+            return fail(OW_ERR_INVALID, "cascade %d: tile_length must be positive", idx[i]);
+        if (p.should_generate_spectrum) {  // :68-72
+            const double F = (double)p.fetch_length * 1e3;
+            ow::SpectrumPC pc;
+            pc.seed_x = p.spectrum_seed[0];
+            pc.seed_y = p.spectrum_seed[1];
+            pc.tile_x = p.tile_length[0];
+            pc.tile_y = p.tile_length[1];
+            pc.alpha = (float)ow_jonswap_alpha((double)p.wind_speed, F);
+            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency((double)p.wind_speed, F);
+            pc.wind_speed = p.wind_speed;
+            pc.angle = (float)((double)p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
+            pc.depth = c->depth;
+            pc.swell = p.swell;
+            pc.detail = p.detail;
+            pc.spread = p.spread;
+            OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
+            p.should_generate_spectrum = 0;
+        }
+        ow::CascadeFrame &cf = args.c[i];
+        cf.tile_x = p.tile_length[0];
+        cf.tile_y = p.tile_length[1];
+        cf.time = (float)p.time;  // push constants are FP32 (render_context.gd:131-134)
+        cf.whitecap = p.whitecap;
+        cf.foam_grow_rate = (float)p.foam_grow_rate;
+        cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
+        cf.cascade = idx[i];
+    }
+    hipEvent_t *ev = nullptr;
+    if (c->timing) {
+        ow_status st = next_events(c, &ev);
+        if (st != OW_OK) return st;
+        OW_HIP(hipEventRecord(ev[0], c->stream));
+    }
+    OW_HIP(ow::launch_pass1(c->n, count, args, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
+    if (ev) OW_HIP(hipEventRecord(ev[1], c->stream));
+    OW_HIP(ow::launch_pass2(c->n, count, args, c->buf, c->stream));  // rows + unpack (:82-85)
+    if (ev) OW_HIP(hipEventRecord(ev[2], c->stream));
+    return OW_OK;
+}
+
+ow_status check_cascade(const ow_context *c, int cascade) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (cascade < 0 || cascade >= c->layers) return fail(OW_ERR_INVALID, "cascade %d out of range [0,%d)", cascade, c->layers);
+    return OW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ow_last_error(void) { return g_last_error.c_str(); }
+int32_t ow_abi_version(void) { return OW_ABI_VERSION; }
+
+double ow_jonswap_alpha(double wind_speed, double fetch_length_m) {  // wave_generator.gd:116-117
+    return 0.076 * std::pow(wind_speed * wind_speed / (fetch_length_m * kHostG), 0.22);
+}
+double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_m) {  // wave_generator.gd:120-121
+    return 22.0 * std::pow(kHostG * kHostG / (wind_speed * fetch_length_m), 1.0 / 3.0);
+}
+
+void ow_cascade_params_default(ow_cascade_params *p) {  // wave_cascade_parameters.gd:7-42
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->tile_length[0] = p->tile_length[1] = 50.0f;
+    p->displacement_scale = 1.0f;
+    p->normal_scale = 1.0f;
+    p->wind_speed = 20.0f;
+    p->wind_direction = 0.0f;
+    p->fetch_length = 550.0f;
+    p->swell = 0.8f;
+    p->spread = 0.2f;
+    p->detail = 1.0f;
+    p->whitecap = 0.5f;
+    p->foam_amount = 5.0f;
+    p->should_generate_spectrum = 1;
+}
+
+ow_status ow_create(const ow_config *cfg, ow_context **out) {
+    if (!cfg || !out) return fail(OW_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (!ow::supported_map_size(cfg->map_size))
+        return fail(OW_ERR_INVALID, "map_size %d unsupported (128, 256, 512, 1024, 2048)", cfg->map_size);
+    if (cfg->num_cascades < 1 || cfg->num_cascades > OW_MAX_CASCADES)
+        return fail(OW_ERR_INVALID, "num_cascades %d outside [1,%d]", cfg->num_cascades, OW_MAX_CASCADES);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(OW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    int dev = cfg->device_id;
+    if (dev < 0) OW_HIP(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(OW_ERR_INVALID, "device_id %d >= device count %d", dev, ndev);
+    OW_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    OW_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OW_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+
+    ow_context *c = new (std::nothrow) ow_context();
+    if (!c) return fail(OW_ERR_NOMEM, "out of host memory");
+    c->n = cfg->map_size;
+    c->cascades = cfg->num_cascades;
+    c->layers = cfg->num_cascades < 2 ? 2 : cfg->num_cascades;  // init_gpu(maxi(2, n)), water.gd:91
+    c->device = dev;
+    c->depth = cfg->depth > 0.0f ? cfg->depth : 20.0f;  // DEPTH, wave_generator.gd:6
+
+    auto bail = [&](ow_status st) {
+        ow_destroy(c);
+        return st;
+    };
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(OW_ERR_HIP, "hipStreamCreate failed"));
+        c->own_stream = true;
+    }
+    const size_t pl = plane(c), L = (size_t)c->layers;
+#define OW_ALLOC(ptr, bytes)                                                                              \
+    if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess)                                                \
+        return bail(fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #ptr, (size_t)(bytes)));
+    OW_ALLOC(c->buf.h0, L * pl * sizeof(ow::f32x4));                  // spectrum (R32G32B32A32_SFLOAT, :31)
+    OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
+    OW_ALLOC(c->buf.T, L * pl * ow::kLayers * sizeof(ow::cplx));      // half of the reference's fft_buffer (:33)
+    if (cfg->displacement_map) {
+        c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
+    } else {
+        OW_ALLOC(c->buf.disp, L * pl * sizeof(ow::u16x4));            // R16G16B16A16_SFLOAT (:34)
+        c->own_disp = true;
+    }
+    if (cfg->normal_map) {
+        c->buf.norm = (ow::u16x4 *)cfg->normal_map;
+    } else {
+        OW_ALLOC(c->buf.norm, L * pl * sizeof(ow::u16x4));            // (:35)
+        c->own_norm = true;
+    }
+    if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
+    std::vector<ow::cplx> tw;
+    ow::make_twiddles(c->n, tw);
+    OW_ALLOC(c->tw_dev, tw.size() * sizeof(ow::cplx));
+#undef OW_ALLOC
+    c->buf.tw = c->tw_dev;
+    // Vulkan images start undefined; foam must start from a defined state: zero
+    if (hipMemcpyAsync(c->tw_dev, tw.data(), tw.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.norm, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::f32x4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return bail(fail(OW_ERR_HIP, "initial upload failed: %s", hipGetErrorString(hipGetLastError())));
+    *out = c;
+    return OW_OK;
+}
+
+void ow_destroy(ow_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->buf.h0);
+    (void)hipFree(c->buf.omega);
+    (void)hipFree(c->buf.T);
+    if (c->own_disp) (void)hipFree(c->buf.disp);
+    if (c->own_norm) (void)hipFree(c->buf.norm);
+    (void)hipFree(c->buf.f32);
+    (void)hipFree(c->tw_dev);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
+    if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+    if (count < 1 || count > c->cascades)  // assert(parameters.size() != 0), :91
+        return fail(OW_ERR_INVALID, "count %d outside [1,%d]", count, c->cascades);
+    OW_HIP(hipSetDevice(c->device));
+    if (c->pass_num_cascades_remaining != 0) {  // :94-98
+        int idx[OW_MAX_CASCADES];
+        for (int i = 0; i < c->pass_num_cascades_remaining; ++i) idx[i] = i;
+        ow_status st = enqueue(c, c->pass_parameters, idx, c->pass_num_cascades_remaining);
+        if (st != OW_OK) return st;
+        c->pass_num_cascades_remaining = 0;
+    }
+    for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
+        ow_cascade_params &p = params[i];
+        p.time += delta;
+        p.foam_grow_rate = delta * (double)p.foam_amount * 7.5;
+        const double d = 10.0 - (double)p.foam_amount;
+        p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
+    }
+    c->pass_parameters = params;  // :108
+    c->pass_num_cascades_remaining = count;  // :109
+    return OW_OK;
+}
+
+ow_status ow_process(ow_context *c) {  // :56-63
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (c->pass_num_cascades_remaining == 0) return OW_OK;
+    OW_HIP(hipSetDevice(c->device));
+    c->pass_num_cascades_remaining -= 1;
+    const int idx = c->pass_num_cascades_remaining;
+    return enqueue(c, c->pass_parameters, &idx, 1);
+}
+
+ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
+    ow_status st = ow_update(c, delta, params, count);
+    if (st != OW_OK) return st;
+    int idx[OW_MAX_CASCADES];
+    for (int i = 0; i < count; ++i) idx[i] = count - 1 - i;  // same order _process would take
+    st = enqueue(c, params, idx, count);
+    if (st != OW_OK) return st;
+    c->pass_num_cascades_remaining = 0;
+    return OW_OK;
+}
+
+ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
+    if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
+    for (int f = 0; f < frames; ++f) {
+        ow_status st = ow_update_all(c, delta, params, count);
+        if (st != OW_OK) return st;
+    }
+    return OW_OK;
+}
+
+int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_cascades_remaining : 0; }
+
+ow_status ow_sync(ow_context *c) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    OW_HIP(hipSetDevice(c->device));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_get_device_ptrs(ow_context *c, void **disp, void **norm, size_t *stride) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (disp) *disp = c->buf.disp;
+    if (norm) *norm = c->buf.norm;
+    if (stride) *stride = plane(c) * sizeof(ow::u16x4);
+    return OW_OK;
+}
+
+ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    OW_HIP(hipSetDevice(c->device));
+    const size_t bytes = plane(c) * sizeof(ow::u16x4);
+    if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
+    if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_set_normal_map(ow_context *c, int32_t cascade, const void *norm) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    if (!norm) return fail(OW_ERR_INVALID, "null normal map");
+    OW_HIP(hipSetDevice(c->device));
+    OW_HIP(hipMemcpyAsync(c->buf.norm + cascade * plane(c), norm, plane(c) * sizeof(ow::u16x4), hipMemcpyHostToDevice, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_get_maps_f32(ow_context *c, int32_t cascade, float *out) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    if (!c->buf.f32) return fail(OW_ERR_STATE, "context was created without OW_FLAG_DEBUG_F32");
+    if (!out) return fail(OW_ERR_INVALID, "null output");
+    OW_HIP(hipSetDevice(c->device));
+    OW_HIP(hipMemcpyAsync(out, c->buf.f32 + cascade * plane(c) * 8, plane(c) * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omega) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    OW_HIP(hipSetDevice(c->device));
+    if (h0) OW_HIP(hipMemcpyAsync(h0, c->buf.h0 + cascade * plane(c), plane(c) * sizeof(ow::f32x4), hipMemcpyDeviceToHost, c->stream));
+    if (omega) OW_HIP(hipMemcpyAsync(omega, c->buf.omega + cascade * plane(c), plane(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    if (!out) return fail(OW_ERR_INVALID, "null output");
+    OW_HIP(hipSetDevice(c->device));
+    const size_t pl = plane(c), n = (size_t)c->n;
+    std::vector<ow::cplx> t(pl * ow::kLayers);
+    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + cascade * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    // device layout T[x'][y][layer]  ->  reference half-0-after-transpose layout [layer][row = x'][col = y]
+    for (size_t xp = 0; xp < n; ++xp)
+        for (size_t y = 0; y < n; ++y)
+            for (int l = 0; l < ow::kLayers; ++l) {
+                const ow::cplx v = t[(xp * n + y) * ow::kLayers + l];
+                float *o = out + (((size_t)l * n + xp) * n + y) * 2;
+                o[0] = v.x;
+                o[1] = v.y;
+            }
+    return OW_OK;
+}
+
+ow_status ow_timing_enable(ow_context *c, int32_t enable) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (!enable) {
+        ow_status st = collect_timing(c);
+        if (st != OW_OK) return st;
+    }
+    c->timing = enable != 0;
+    return OW_OK;
+}
+
+ow_status ow_timing_read(ow_context *c, float *p1, float *p2, int32_t *launches, int32_t reset) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    ow_status st = collect_timing(c);
+    if (st != OW_OK) return st;
+    const int n = c->t_launches;
+    if (p1) *p1 = n ? (float)(c->t1_ms / n) : 0.0f;
+    if (p2) *p2 = n ? (float)(c->t2_ms / n) : 0.0f;
+    if (launches) *launches = n;
+    if (reset) {
+        c->t1_ms = c->t2_ms = 0;
+        c->t_launches = 0;
+    }
+    return OW_OK;
+}
+
+}  // extern "C"

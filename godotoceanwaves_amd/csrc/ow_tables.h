@@ -1,0 +1,37 @@
+// ow_tables.h -- host-side construction of the constant twiddle table (replaces the reference's
+// fft_butterfly.glsl dispatch, wave_generator.gd:52-54: the Stockham read indices are closed-form in
+// this design, only exp(+2*pi*i*p*k/n_j) per radix pass is tabulated, in FP64 rounded once to FP32).
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "ow_device.h"
+
+namespace ow {
+
+template <int N>
+inline void fill_twiddles(std::vector<cplx> &tw) {
+    tw.assign(plan_tw_total(N) > 0 ? plan_tw_total(N) : 1, cplx{1.0f, 0.0f});
+    constexpr int S = plan_S(N);
+    for (int j = 0; j + 1 < S; ++j) {
+        const int R = plan_R(N, j), m = plan_m(N, j), n = plan_n(N, j), off = plan_tw_off(N, j);
+        for (int k = 1; k < R; ++k)
+            for (int p = 0; p < m; ++p) {
+                const double a = 2.0 * 3.14159265358979323846 * (double)((long long)p * k % n) / (double)n;
+                tw[off + (k - 1) * m + p] = cplx{(float)std::cos(a), (float)std::sin(a)};
+            }
+    }
+}
+
+inline bool make_twiddles(int n, std::vector<cplx> &tw) {
+    switch (n) {
+        case 128: fill_twiddles<128>(tw); return true;
+        case 256: fill_twiddles<256>(tw); return true;
+        case 512: fill_twiddles<512>(tw); return true;
+        case 1024: fill_twiddles<1024>(tw); return true;
+        case 2048: fill_twiddles<2048>(tw); return true;
+    }
+    return false;
+}
+
+}  // namespace ow

@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's generator interface on top of the C-ABI.
+
+`WaveCascadeParameters` mirrors assets/water/wave_cascade_parameters.gd (same field names, defaults,
+clamps and dirty-flag setters); `WaveGenerator` mirrors assets/water/wave_generator.gd (map_size,
+init_gpu, update, _process, descriptors, JONSWAP statics).  All compute happens in
+libocean_waves.so (HIP, gfx950); this file holds no numerics beyond packing the parameter record.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import OW_FLAG_DEBUG_F32, ow_cascade_params, ow_config
+
+G = 9.81       # wave_generator.gd:5
+DEPTH = 20.0   # wave_generator.gd:6
+
+
+def _dirty(name, clamp=None):
+    """@export var with `set(value): ...; should_generate_spectrum = true` (wave_cascade_parameters.gd:7-35)"""
+    attr = "_" + name
+
+    def getter(self):
+        return getattr(self, attr)
+
+    def setter(self, value):
+        setattr(self, attr, clamp(value) if clamp else value)
+        self.should_generate_spectrum = True
+
+    return property(getter, setter)
+
+
+class WaveCascadeParameters:
+    """wave_cascade_parameters.gd:1-56 (the imgui mirror fields :44-56 are UI-only and omitted)."""
+    tile_length = _dirty("tile_length", lambda v: (float(v[0]), float(v[1])))                 # :7
+    wind_speed = _dirty("wind_speed", lambda v: max(0.0001, float(v)))                        # :15
+    wind_direction = _dirty("wind_direction", float)                                          # :17
+    fetch_length = _dirty("fetch_length", lambda v: max(0.0001, float(v)))                    # :20
+    swell = _dirty("swell", float)                                                            # :22
+    spread = _dirty("spread", float)                                                          # :25
+    detail = _dirty("detail", float)                                                          # :28
+    whitecap = _dirty("whitecap", float)      # yes, the reference re-generates on these too    :32-35
+    foam_amount = _dirty("foam_amount", float)
+
+    def __init__(self, **kw):
+        self.displacement_scale = 1.0   # :9  (consumer-side only; no dirty flag)
+        self.normal_scale = 1.0         # :11
+        self.tile_length = (50.0, 50.0)
+        self.wind_speed = 20.0
+        self.wind_direction = 0.0
+        self.fetch_length = 550.0
+        self.swell = 0.8
+        self.spread = 0.2
+        self.detail = 1.0
+        self.whitecap = 0.5
+        self.foam_amount = 5.0
+        self.spectrum_seed = (0, 0)            # :37 Vector2i.ZERO
+        self.should_generate_spectrum = True   # :38
+        self.time = 0.0                        # :40
+        self.foam_grow_rate = 0.0              # :41
+        self.foam_decay_rate = 0.0             # :42
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(f"WaveCascadeParameters has no field {k!r}")
+            setattr(self, k, v)
+
+    def _pack(self, c):
+        c.tile_length[0], c.tile_length[1] = self.tile_length
+        c.displacement_scale, c.normal_scale = self.displacement_scale, self.normal_scale
+        c.wind_speed, c.wind_direction, c.fetch_length = self.wind_speed, self.wind_direction, self.fetch_length
+        c.swell, c.spread, c.detail = self.swell, self.spread, self.detail
+        c.whitecap, c.foam_amount = self.whitecap, self.foam_amount
+        c.spectrum_seed[0], c.spectrum_seed[1] = int(self.spectrum_seed[0]), int(self.spectrum_seed[1])
+        c.should_generate_spectrum = 1 if self.should_generate_spectrum else 0
+        c.time, c.foam_grow_rate, c.foam_decay_rate = self.time, self.foam_grow_rate, self.foam_decay_rate
+
+    def _unpack_runtime(self, c):
+        # fields the generator mutates inside the parameter object (wave_generator.gd:72,103-106)
+        self.time, self.foam_grow_rate, self.foam_decay_rate = c.time, c.foam_grow_rate, c.foam_decay_rate
+        self.should_generate_spectrum = bool(c.should_generate_spectrum)
+
+
+class _Descriptor:
+    """stand-in for RenderingContext.Descriptor (render_context.gd:23-28): `.rid` is the device pointer"""
+
+    def __init__(self, rid, layer_stride):
+        self.rid, self.layer_stride = rid, layer_stride
+
+
+class WaveGenerator:
+    """assets/water/wave_generator.gd.  Typical use, as in water.gd:89-91,112-114:
+
+        gen = WaveGenerator(); gen.map_size = 1024; gen.init_gpu(max(2, len(parameters)))
+        gen.update(delta, parameters)          # once per simulation tick
+        gen._process(frame_delta)              # once per rendered frame (one cascade each)
+    """
+
+    def __init__(self):
+        self.map_size = 0          # :8
+        self.context = None        # :9  (ow_context*)
+        self.descriptors = {}      # :11
+        self.pass_parameters = []  # :14
+        self._pass_c = None
+        self._lib = None
+        self.depth = DEPTH
+        self.debug_f32 = False
+        self.device_id = -1
+        self.stream = None
+        self.external_maps = (None, None)  # optional caller-owned device buffers (displacement, normal)
+        self.num_cascades = 0
+
+    @property
+    def pass_num_cascades_remaining(self):  # :15
+        return self._lib.ow_cascades_remaining(self.context) if self.context else 0
+
+    # ---- init_gpu (:17-54) ------------------------------------------------------------------------
+    def init_gpu(self, num_cascades):
+        self._lib = _lib.load()
+        if self.context:
+            self.free()
+        cfg = ow_config(map_size=int(self.map_size), num_cascades=int(num_cascades), device_id=self.device_id,
+                        depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
+                        normal_map=self.external_maps[1], flags=OW_FLAG_DEBUG_F32 if self.debug_f32 else 0)
+        ctx = C.c_void_p()
+        _lib.check(self._lib.ow_create(C.byref(cfg), C.byref(ctx)))
+        self.context = ctx
+        self.num_cascades = int(num_cascades)
+        d, n, stride = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _lib.check(self._lib.ow_get_device_ptrs(ctx, C.byref(d), C.byref(n), C.byref(stride)))
+        self.descriptors = {"displacement_map": _Descriptor(d.value, stride.value),
+                            "normal_map": _Descriptor(n.value, stride.value)}
+
+    # ---- _process (:56-63) --------------------------------------------------------------------------
+    def _process(self, delta=0.0):
+        if not self.context or self.pass_num_cascades_remaining == 0:
+            return
+        idx = self.pass_num_cascades_remaining - 1
+        self.pass_parameters[idx]._pack(self._pass_c[idx])       # parameter objects are live in the reference
+        _lib.check(self._lib.ow_process(self.context))
+        self.pass_parameters[idx]._unpack_runtime(self._pass_c[idx])
+
+    # ---- update (:90-109) ------------------------------------------------------------------------------
+    def _arm(self, fn, delta, parameters):
+        assert len(parameters) != 0                               # :91
+        if not self.context:
+            self.init_gpu(max(2, len(parameters)))                # :92-93
+        if self.pass_num_cascades_remaining:                      # leftovers see the live parameter objects
+            for i in range(self.pass_num_cascades_remaining):
+                self.pass_parameters[i]._pack(self._pass_c[i])
+        prev_py, prev_c, prev_rem = self.pass_parameters, self._pass_c, self.pass_num_cascades_remaining
+        new_c = (ow_cascade_params * len(parameters))()
+        for p, c in zip(parameters, new_c):
+            p._pack(c)
+        _lib.check(fn(self.context, float(delta), new_c, len(parameters)))
+        for i in range(prev_rem):
+            prev_py[i]._unpack_runtime(prev_c[i])
+            if prev_py[i] in parameters:                          # flushed cascade is also in the new set: keep it clean
+                new_c[parameters.index(prev_py[i])].should_generate_spectrum = 0
+        for p, c in zip(parameters, new_c):
+            p._unpack_runtime(c)
+        self.pass_parameters, self._pass_c = list(parameters), new_c
+
+    def update(self, delta, parameters):
+        self._arm(self._lib.ow_update if self._lib else _lib.load().ow_update, delta, parameters)
+
+    def update_all(self, delta, parameters):
+        """throughput mode (not in the reference): update() + every cascade in one pair of launches"""
+        self._arm(self._lib.ow_update_all if self._lib else _lib.load().ow_update_all, delta, parameters)
+
+    def run(self, delta, parameters, frames):
+        """throughput mode: `frames` update_all() ticks enqueued back to back by the C runtime"""
+        fn = self._lib.ow_run if self._lib else _lib.load().ow_run
+        self._arm(lambda ctx, d, arr, cnt: fn(ctx, d, arr, cnt, int(frames)), delta, parameters)
+
+    # ---- teardown (:111-113) -------------------------------------------------------------------------------
+    def free(self):
+        if self.context:
+            self._lib.ow_destroy(self.context)
+            self.context = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # ---- statics (:116-121) -----------------------------------------------------------------------------------
+    @staticmethod
+    def JONSWAP_alpha(wind_speed=20.0, fetch_length=550e3):
+        return _lib.load().ow_jonswap_alpha(wind_speed, fetch_length)
+
+    @staticmethod
+    def JONSWAP_peak_angular_frequency(wind_speed=20.0, fetch_length=550e3):
+        return _lib.load().ow_jonswap_peak_angular_frequency(wind_speed, fetch_length)
+
+    # ---- host read-back helpers (RenderingDevice.texture_get_data equivalents) ------------------------------
+    def sync(self):
+        _lib.check(self._lib.ow_sync(self.context))
+
+    def get_maps(self, cascade):
+        n = self.map_size
+        disp, norm = np.empty((n, n, 4), np.float16), np.empty((n, n, 4), np.float16)
+        _lib.check(self._lib.ow_get_maps(self.context, cascade, disp.ctypes.data, norm.ctypes.data))
+        return disp, norm
+
+    def set_normal_map(self, cascade, normal):
+        a = np.ascontiguousarray(normal, np.float16)
+        assert a.shape == (self.map_size, self.map_size, 4)
+        _lib.check(self._lib.ow_set_normal_map(self.context, cascade, a.ctypes.data))
+
+    def get_maps_f32(self, cascade):
+        out = np.empty((self.map_size, self.map_size, 8), np.float32)
+        _lib.check(self._lib.ow_get_maps_f32(self.context, cascade, out.ctypes.data))
+        return out
+
+    def get_spectrum(self, cascade):
+        n = self.map_size
+        h0, om = np.empty((n, n, 4), np.float32), np.empty((n, n), np.float32)
+        _lib.check(self._lib.ow_get_spectrum(self.context, cascade, h0.ctypes.data, om.ctypes.data))
+        return h0, om
+
+    def get_intermediate(self, cascade):
+        out = np.empty((4, self.map_size, self.map_size, 2), np.float32)
+        _lib.check(self._lib.ow_get_intermediate(self.context, cascade, out.ctypes.data))
+        return out
+
+    def timing(self, enable):
+        _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
+
+    def timing_read(self, reset=True):
+        a, b, n = C.c_float(), C.c_float(), C.c_int32()
+        _lib.check(self._lib.ow_timing_read(self.context, C.byref(a), C.byref(b), C.byref(n), 1 if reset else 0))
+        return a.value, b.value, n.value

@@ -1,0 +1,170 @@
+/*
+ * ocean_waves.h -- C-ABI of the MI355X-native ocean-wave generator (libocean_waves.so).
+ *
+ * Drop-in boundary for ONE path of 2Retr0/GodotOceanWaves: the per-cascade
+ *   spectrum -> time-modulate -> 2-D inverse FFT -> unpack / Jacobian / foam
+ * pipeline that `WaveGenerator` (assets/water/wave_generator.gd) drives through six GLSL compute
+ * shaders (assets/shaders/compute/).  Each entry point names the reference interface it replaces
+ * (file:line, paths relative to the reference checkout).  Plain C: POD structs, pointers and
+ * sizes, int status codes, no callbacks, no exceptions across the boundary.  A context is not
+ * thread-safe: one caller thread per context, exactly like the reference (everything runs on
+ * Godot's main thread, wave_generator.gd:19).
+ *
+ * There is NO CPU fallback: ow_create() fails with OW_ERR_NO_DEVICE when no gfx950-class HIP
+ * device is visible.
+ */
+#ifndef OCEAN_WAVES_H
+#define OCEAN_WAVES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OW_MAX_CASCADES 8 /* MAX_CASCADES, assets/shaders/spatial/water.gdshader:8 */
+#define OW_ABI_VERSION 1
+
+typedef enum ow_status {
+    OW_OK = 0,
+    OW_ERR_INVALID = 1,   /* bad argument (reference: assert, wave_generator.gd:91, render_context.gd:77) */
+    OW_ERR_NO_DEVICE = 2, /* no HIP device / wrong architecture */
+    OW_ERR_HIP = 3,       /* a HIP runtime call failed; see ow_last_error() */
+    OW_ERR_NOMEM = 4,
+    OW_ERR_STATE = 5      /* call order violated (e.g. ow_process with nothing armed is NOT an error: it is a no-op) */
+} ow_status;
+
+/* WaveCascadeParameters -- assets/water/wave_cascade_parameters.gd:7-42.
+ * Field meaning, units and defaults are the reference's; GDScript floats are FP64 and are narrowed
+ * to FP32 when packed into push constants (assets/render_context.gd:131-134), so the FP32 fields
+ * here lose nothing.  `time`, `foam_*_rate` and `should_generate_spectrum` are runtime state that
+ * the generator mutates inside the caller's struct, exactly as wave_generator.gd:72,103-106 does. */
+typedef struct ow_cascade_params {
+    float tile_length[2];     /* metres covered by the tile, default (50, 50)              :7  */
+    float displacement_scale; /* consumer-side only, default 1.0                           :9  */
+    float normal_scale;       /* consumer-side only, default 1.0                           :11 */
+    float wind_speed;         /* m/s, clamped >= 1e-4, default 20                          :15 */
+    float wind_direction;     /* degrees, default 0                                        :17 */
+    float fetch_length;       /* km, clamped >= 1e-4, default 550                          :20 */
+    float swell;              /* [0,2], default 0.8                                        :22 */
+    float spread;             /* [0,1], default 0.2                                        :25 */
+    float detail;             /* [0,1], default 1.0                                        :28 */
+    float whitecap;           /* [0,2], default 0.5                                        :32 */
+    float foam_amount;        /* [0,10], default 5.0                                       :34 */
+    int32_t spectrum_seed[2]; /* Vector2i, offsets the hash lattice                        :37 */
+    int32_t should_generate_spectrum; /* dirty flag, default 1                            :38 */
+    int32_t reserved;
+    double time;              /* seconds; water.gd:32 starts cascade i at 120 + PI*i        :40 */
+    double foam_grow_rate;    /* set by ow_update: delta * foam_amount * 7.5                :41 */
+    double foam_decay_rate;   /* set by ow_update: delta * max(0.5, 10 - foam_amount)*1.15  :42 */
+} ow_cascade_params;
+
+/* Creation parameters -- replaces `wave_generator.map_size = N; wave_generator.init_gpu(C)`
+ * (assets/water/water.gd:89-91, wave_generator.gd:8,17). */
+typedef struct ow_config {
+    int32_t map_size;     /* 128, 256, 512, 1024 (reference set, water.gd:38) or 2048 (beyond the reference) */
+    int32_t num_cascades; /* 1..OW_MAX_CASCADES; like the reference, max(2, n) array layers are allocated (water.gd:91) */
+    int32_t device_id;    /* HIP device ordinal; -1 = current device */
+    float depth;          /* metres; the reference hard-codes DEPTH = 20.0 (wave_generator.gd:6); <= 0 selects 20 */
+    void *stream;         /* hipStream_t to enqueue on; NULL = the context creates its own non-blocking stream */
+    void *displacement_map; /* optional caller-owned DEVICE buffer, layers*N*N*8 bytes (RGBA16F); NULL = context allocates */
+    void *normal_map;       /* optional caller-owned DEVICE buffer, same size; its .a channel is the foam state */
+    uint32_t flags;       /* OW_FLAG_* */
+} ow_config;
+
+#define OW_FLAG_DEBUG_F32 1u /* also keep 8 pre-quantisation FP32 channels per texel (parity tests) */
+
+typedef struct ow_context ow_context;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* WaveGenerator.init_gpu (wave_generator.gd:17-54): allocates spectrum, FFT intermediate and the two
+ * RGBA16F output arrays; uploads the twiddle tables (replaces the fft_butterfly dispatch, :52-54). */
+ow_status ow_create(const ow_config *config, ow_context **out);
+
+/* NOTIFICATION_PREDELETE -> context.free() (wave_generator.gd:111-113). NULL is allowed. */
+void ow_destroy(ow_context *ctx);
+
+/* Defaults of wave_cascade_parameters.gd:7-38. */
+void ow_cascade_params_default(ow_cascade_params *p);
+
+/* ---- the per-tick surface ---------------------------------------------------------------------- */
+
+/* WaveGenerator.update(delta, parameters) (wave_generator.gd:90-109):
+ *   1. cascades armed by the previous call and not yet processed are flushed now, indices
+ *      0..remaining-1, with the PREVIOUS parameter array (:94-98);
+ *   2. for every cascade: time += delta, foam_grow_rate, foam_decay_rate (:101-106);
+ *   3. all `count` cascades are armed (:108-109).
+ * `params` is borrowed until the armed cascades are drained (the reference keeps the Array reference). */
+ow_status ow_update(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
+
+/* WaveGenerator._process (wave_generator.gd:56-63): processes ONE armed cascade (highest index
+ * first) -- the reference's one-cascade-per-rendered-frame load balancing.  No-op when nothing is armed. */
+ow_status ow_process(ow_context *ctx);
+
+/* Throughput mode: ow_update() followed by all armed cascades in ONE pair of kernel launches
+ * (results identical to calling ow_process() `count` times). */
+ow_status ow_update_all(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
+
+/* `frames` consecutive ow_update_all() ticks with the same delta, enqueued back to back (the reference's
+ * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times. */
+ow_status ow_run(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count, int32_t frames);
+
+/* Number of armed, unprocessed cascades (pass_num_cascades_remaining, wave_generator.gd:15). */
+int32_t ow_cascades_remaining(const ow_context *ctx);
+
+/* Blocks until everything enqueued by this context has finished. */
+ow_status ow_sync(ow_context *ctx);
+
+/* ---- outputs: descriptors[&'displacement_map'/'normal_map'] (wave_generator.gd:34-35, water.gd:95-96) ---- */
+
+/* Device pointers of the two RGBA16F array textures: layer-major [layer][row][col][4 x fp16],
+ * layer stride = N*N*8 bytes.  Pixel (col = id.x, row = id.y) holds exactly what fft_unpack.glsl:50,67
+ * imageStore()s at ivec3(id.x, id.y, cascade) -- including the transposed orientation that results
+ * from skipping the second transpose (wave_generator.gd:77-82).  normal = (gradient.x, gradient.y,
+ * dhx_dx, foam). */
+ow_status ow_get_device_ptrs(ow_context *ctx, void **displacement_map, void **normal_map, size_t *layer_stride_bytes);
+
+/* Host copy of one layer of each map in RenderingDevice.texture_update(tex, layer, bytes) layout
+ * (row-major, 8 bytes per texel, N*N*8 bytes each).  Either pointer may be NULL.  Synchronises. */
+ow_status ow_get_maps(ow_context *ctx, int32_t cascade, void *displacement_rgba16f, void *normal_rgba16f);
+
+/* Foam / simulation state: the only persistent state besides `time` is the normal map (foam = .a,
+ * FP16).  ow_set_normal_map uploads N*N*8 bytes into one layer (checkpoint/restore, re-sharding). */
+ow_status ow_set_normal_map(ow_context *ctx, int32_t cascade, const void *normal_rgba16f);
+
+/* ---- parity / debug ------------------------------------------------------------------------------ */
+
+/* 8 FP32 channels per texel before FP16 quantisation: [hx, hy, hz, grad_x, grad_y, dhx_dx, foam, jacobian],
+ * N*N*8 floats.  Requires OW_FLAG_DEBUG_F32. */
+ow_status ow_get_maps_f32(ow_context *ctx, int32_t cascade, float *out);
+
+/* The `spectrum` texture (wave_generator.gd:31; float4 = h0(k), conj(h0(-k)), N*N*4 floats) and the
+ * FP32 dispersion plane omega(k) (N*N floats) the frame kernels consume.  Either may be NULL. */
+ow_status ow_get_spectrum(ow_context *ctx, int32_t cascade, float *h0, float *omega);
+
+/* The transposed intermediate after the first row pass, converted to the reference's layout
+ * fft_buffer half 0 after transpose.glsl: [layer][row][col] complex, 4*N*N*2 floats. */
+ow_status ow_get_intermediate(ow_context *ctx, int32_t cascade, float *out);
+
+/* ---- host math: static funcs of WaveGenerator (wave_generator.gd:116-121), FP64 ---------------------- */
+double ow_jonswap_alpha(double wind_speed, double fetch_length_m);
+double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_m);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+
+/* Average duration (ms) of the two frame kernels over the launches made since the last reset,
+ * measured with hipEvents on the context's stream.  Enable first; enabling adds two event records
+ * per launch, so throughput runs keep it off. */
+ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
+ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char *ow_last_error(void);
+int32_t ow_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCEAN_WAVES_H */

@@ -1,0 +1,176 @@
+"""Parity tests proper: the HIP path (through the C-ABI / WaveGenerator mirror) against the CPU oracle on
+the same seeded inputs.  Tolerances are the ones of north_star / SURVEY.md 8c and are written where used."""
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, _lib
+from godotoceanwaves_amd.presets import DEPTH, UPDATE_DELTA, cascade_preset
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_gen(n, cascade_ids, debug=True):
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.debug_f32 = debug
+    gen.init_gpu(max(2, len(cascade_ids)))
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in cascade_ids]
+    return gen, params
+
+
+@pytest.mark.parametrize("n", [128, 256, 512, 1024])
+def test_spectrum_and_omega(n):
+    """spectrum_compute.glsl: h0 within 2e-5 (max-norm relative; libm vs device libm ulps), omega BIT-exact."""
+    ids = [0, 2]
+    gen, params = make_gen(n, ids)
+    gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    for i, ci in enumerate(ids):
+        p = cascade_preset(ci)
+        h0, om = gen.get_spectrum(i)
+        ref = O.spectrum_compute(n, H.spectrum_pc(p))
+        assert np.isfinite(h0).all()
+        assert H.relmax(h0, ref) < 2e-5
+        om_ref = O.omega(n, p["tile_length"], DEPTH)
+        mism = int((om.view(np.uint32) != om_ref.view(np.uint32)).sum())
+        assert mism <= 2, f"{mism} omega texels differ"  # P(double-rounding disagreement) ~ 2^-28 per texel
+
+
+@pytest.mark.parametrize("n,ids", [(128, [0]), (256, [0, 1, 2, 3]), (512, [2, 4]), (1024, [2])])
+def test_frame_parity_vs_oracle(n, ids):
+    """3 frames of modulate + IFFT + unpack: FP32 channels <= 1e-4 max-norm relative, FP16 maps <= 1 ulp,
+    intermediate (after the first row pass + transpose) <= 1e-5."""
+    gen, params = make_gen(n, ids)
+    og = H.oracle_generator(n, ids)
+    for frame in range(3):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+        gen.sync()
+        for i in range(len(ids)):
+            assert params[i].time == og.params[i].time
+            f32, ref = gen.get_maps_f32(i), og.f32(i)
+            for c, name in enumerate(H.CHANNELS):
+                if name == "foam":
+                    assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (frame, i, name)
+                else:
+                    assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (frame, i, name)
+            disp, norm = gen.get_maps(i)
+            assert H.fp16_close(disp, og.displacement(i)) <= 1.0
+            assert H.fp16_close(norm[..., :3], og.normal(i)[..., :3]) <= 1.0
+            assert np.abs(norm[..., 3].astype(np.float64) - og.normal(i)[..., 3].view(np.float16).astype(np.float64)).max() <= H.TOL_FOAM_ABS
+    # the fft_buffer contents after pass 1 (reference: fft_compute + transpose, half 0)
+    inter = gen.get_intermediate(len(ids) - 1)
+    p = cascade_preset(ids[-1])
+    spec = og.spectrum(len(ids) - 1)
+    x = O.spectrum_modulate(n, p["tile_length"], DEPTH, np.float32(og.params[len(ids) - 1].time), spec)
+    tab = O.fft_butterfly(n)
+    ref_half0 = O.fft_rows(n, tab, x).transpose(0, 2, 1, 3)
+    assert H.relmax(inter, ref_half0) < 1e-5
+
+
+def test_process_one_cascade_per_frame_equals_update_all():
+    """wave_generator.gd:56-63,90-109: update() arms, _process() drains highest index first, the next update()
+    flushes leftovers 0..remaining-1 -- results identical (bitwise) to the batched launch."""
+    n, ids = 256, [0, 1, 2]
+    gen_a, pa = make_gen(n, ids, debug=False)
+    gen_b, pb = make_gen(n, ids, debug=False)
+    for tick in range(3):
+        gen_a.update_all(UPDATE_DELTA, pa)
+        gen_b.update(UPDATE_DELTA, pb)
+        assert gen_b.pass_num_cascades_remaining == 3
+        if tick != 1:
+            for k in range(3):
+                gen_b._process(0.0)
+                assert gen_b.pass_num_cascades_remaining == 2 - k
+        else:
+            gen_b._process(0.0)  # only cascade 2; cascades 0,1 are flushed by the next update()
+            assert gen_b.pass_num_cascades_remaining == 2
+    gen_b.update(UPDATE_DELTA, pb)   # flush
+    gen_a.update_all(UPDATE_DELTA, pa)
+    for k in range(3):
+        gen_b._process(0.0)
+    gen_a.sync(); gen_b.sync()
+    for i in range(3):
+        da, na = gen_a.get_maps(i)
+        db, nb = gen_b.get_maps(i)
+        assert np.array_equal(da.view(np.uint16), db.view(np.uint16))
+        assert np.array_equal(na.view(np.uint16), nb.view(np.uint16))
+        assert pa[i].time == pb[i].time and not pb[i].should_generate_spectrum
+
+
+def test_dirty_flag_regenerates_spectrum():
+    n = 256
+    gen, params = make_gen(n, [0, 1], debug=False)
+    gen.update_all(UPDATE_DELTA, params); gen.sync()
+    h0_before, _ = gen.get_spectrum(0)
+    params[0].wind_speed = 14.0            # setter sets should_generate_spectrum (wave_cascade_parameters.gd:15)
+    assert params[0].should_generate_spectrum
+    gen.update_all(UPDATE_DELTA, params); gen.sync()
+    h0_after, _ = gen.get_spectrum(0)
+    assert not params[0].should_generate_spectrum and not np.array_equal(h0_before, h0_after)
+    p = cascade_preset(0); p["wind_speed"] = 14.0
+    assert H.relmax(h0_after, O.spectrum_compute(n, H.spectrum_pc(p))) < 2e-5
+
+
+def test_foam_state_roundtrip():
+    """the only persistent state besides `time` is normal.a (FP16): save/restore reproduces the trajectory bitwise"""
+    n = 256
+    gen, params = make_gen(n, [0, 2], debug=False)
+    for _ in range(4):
+        gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    saved = [gen.get_maps(i)[1].copy() for i in range(2)]
+    times = [p.time for p in params]
+    for _ in range(3):
+        gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    final = [gen.get_maps(i)[1].copy() for i in range(2)]
+    assert float(final[0][..., 3].max()) > 0.0  # foam exists for cascade 0 (foam_amount 8)
+    gen2, params2 = make_gen(n, [0, 2], debug=False)
+    for i in range(2):
+        params2[i].time = times[i]
+    gen2.update_all(0.0, params2)          # generates the spectra; one throw-away frame
+    for i in range(2):
+        gen2.set_normal_map(i, saved[i])
+    for _ in range(3):
+        gen2.update_all(UPDATE_DELTA, params2)
+    gen2.sync()
+    for i in range(2):
+        assert np.array_equal(gen2.get_maps(i)[1].view(np.uint16), final[i].view(np.uint16))
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_full_size_properties(n):
+    """BASELINE sizes, size-independent checks: (a) against NumPy's FP64 ifft2 fed with the device's own
+    h0/omega (identity: result == (N^2 ifft2 X)^T) within 1e-4; (b) displacement mean == DC term."""
+    import np_twin as T
+    ids = [1]
+    gen, params = make_gen(n, ids)
+    gen.update_all(UPDATE_DELTA, params); gen.sync()
+    h0, om = gen.get_spectrum(0)
+    p = cascade_preset(ids[0])
+    t32 = np.float32(params[0].time)
+    phase32 = om * t32                                   # the FP32-rounded product of spectrum_modulate.glsl:65
+    x = T.modulate(n, p["tile_length"], DEPTH, float(t32),
+                   (h0[..., 0] + 1j * h0[..., 1]).astype(np.complex128), (h0[..., 2] + 1j * h0[..., 3]).astype(np.complex128),
+                   omega=phase32.astype(np.float64) / float(t32))
+    ref = T.unpack(T.ifft2_ref(x), p["whitecap"], params[0].foam_grow_rate, params[0].foam_decay_rate)
+    f32 = gen.get_maps_f32(0)
+    for c, name in enumerate(H.CHANNELS):
+        if name == "foam":
+            assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS
+        else:
+            assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, name
+
+
+def test_invalid_arguments_are_errors():
+    gen, params = make_gen(256, [0, 1], debug=False)
+    L = _lib.load()
+    with pytest.raises(_lib.OceanWavesError):
+        gen.update_all(UPDATE_DELTA, params + [WaveCascadeParameters()])  # more cascades than allocated
+    with pytest.raises(_lib.OceanWavesError):
+        gen.get_maps_f32(0)                                             # context created without DEBUG_F32
+    with pytest.raises(_lib.OceanWavesError):
+        gen.get_maps(5)
