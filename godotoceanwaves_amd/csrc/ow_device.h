@@ -19,9 +19,11 @@
 
 #if defined(__HIPCC__)
 #define OW_DEV __device__ __forceinline__
+#define OW_HD __host__ __device__ __forceinline__
 #define OW_DEVICE_BUILD 1
 #else
 #define OW_DEV inline
+#define OW_HD inline
 #define OW_DEVICE_BUILD 0
 #endif
 
@@ -53,6 +55,13 @@ constexpr int plan_n(int N, int j) { return N / plan_s(N, j); }                 
 constexpr int plan_m(int N, int j) { return plan_n(N, j) / plan_R(N, j); }
 constexpr int plan_B(int N, int j) { return (N / plan_R(N, j)) / plan_T(N); }  // butterflies per lane
 constexpr int plan_rows_per_wave(int N) { return 64 / plan_T(N); }
+// pass 1 workgroup: as many waves as it takes to cover 4 consecutive rows (the row quad that forms one
+// contiguous run of the transposed intermediate)
+constexpr int plan_p1_waves(int N) { return plan_rows_per_wave(N) >= 4 ? 1 : 4 / plan_rows_per_wave(N); }
+constexpr int plan_p1_rows(int N) { return plan_p1_waves(N) * plan_rows_per_wave(N); }
+// LDS row region: FFT exchange image (N + N/16 complex) or staging image (N/2 float4), + 64 B so that the
+// four row regions of a quad start on different 16-byte bank slots
+constexpr int plan_region_cplx(int N) { return N + N / 16 + 8; }
 // twiddle table: for every non-last stage j a [R_j - 1][m_j] block of exp(+2*pi*i*p*k/n_j)
 constexpr int plan_tw_size(int N, int j) { return (plan_R(N, j) - 1) * plan_m(N, j); }
 constexpr int plan_tw_off(int N, int j) { return j == 0 ? 0 : plan_tw_off(N, j - 1) + plan_tw_size(N, j - 1); }
@@ -60,7 +69,7 @@ constexpr int plan_tw_total(int N) { return plan_tw_off(N, plan_S(N) - 1); }
 // LDS: one padded row buffer per row carried by the wave
 constexpr int lds_slot(int e) { return e + (e >> 4); }
 constexpr int plan_row_slots(int N) { return N + N / 16; }
-constexpr int plan_lds_cplx(int N) { return plan_row_slots(N) * plan_rows_per_wave(N); }
+constexpr int plan_lds_cplx(int N) { return plan_region_cplx(N) * plan_rows_per_wave(N); }
 
 // register slot that holds output k of an in-place radix-R butterfly (see dft<R>)
 constexpr int dft_pos(int R, int k) { return R == 16 ? 4 * (k % 4) + k / 4 : (R == 8 ? 2 * (k % 4) + k / 4 : k); }
@@ -306,6 +315,15 @@ struct FrameArgs {
     CascadeFrame c[kMaxCascades];
 };
 
+// Intermediate layout (device-private): two planes, one per packed layer PAIR p = layer/2,
+//   T[c][p][y/8][x'][y%8] of float4 = (layer 2p, layer 2p+1) complex FP32   (16-byte units).
+// One 128-byte line = 8 consecutive y of one x'.  Pass 1 stages a pair through LDS and every wave
+// store instruction writes 16 x' x (4 rows x 16 B = one full 64-byte write request); pass 2 lane octets
+// read whole 128-byte lines.
+OW_HD size_t t_unit(int n, int pair, int xp, int y) {  // index in f32x4 units inside one cascade
+    return ((((size_t)pair * (n >> 3) + (y >> 3)) * n + xp) << 3) + (y & 7);
+}
+
 // k-vector component exactly as spectrum_modulate.glsl:60 writes it
 OW_DEV float modulate_kcomp(int id, int n, float tile) {
     return ((((float)id - (float)n * 0.5f) * 2.0f) * kPi) / tile;
@@ -362,15 +380,28 @@ struct Pass1 {
         }
     }
 
-    // out[L][...] -> T[c][x'][y][L] : one 32-byte granule per (x', y)
-    static OW_DEV void store(const cplx (*out)[P], int t, int y, cplx *__restrict__ Tc) {
+    // Transposed store of one layer pair (a = layer 2p, b = layer 2p+1), in two rounds r = 0, 1 that each
+    // cover half of the x' range.  stage_write: every lane puts its own row's results, x'-ordered, into
+    // its row region (16 B per x').  After a workgroup barrier, stage_store: thread tau of the block takes
+    // (row q = tau % 4 of the quad, x' = tau / 4 + ...), so that consecutive lanes write consecutive
+    // 16-byte units of T.  A second barrier must follow before the regions are written again.
+    static OW_DEV void stage_write(const cplx *a, const cplx *b, int t, int r, cplx *lds_row) {
+        f32x4 *st = reinterpret_cast<f32x4 *>(lds_row);
 #pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int xp = t + T * o;
-            const int sl = OutMap<N>::slot_of(o);
-            f32x4 *g = reinterpret_cast<f32x4 *>(Tc + ((size_t)xp * N + y) * kLayers);
-            g[0] = f32x4{out[0][sl].x, out[0][sl].y, out[1][sl].x, out[1][sl].y};
-            g[1] = f32x4{out[2][sl].x, out[2][sl].y, out[3][sl].x, out[3][sl].y};
+        for (int oo = 0; oo < P / 2; ++oo) {
+            const int sl = OutMap<N>::slot_of(r * (P / 2) + oo);
+            st[t + T * oo] = f32x4{a[sl].x, a[sl].y, b[sl].x, b[sl].y};
+        }
+    }
+    // tau = thread index in the block, row0 = first map row of the block, Tc = this cascade's T
+    static OW_DEV void stage_store(int tau, int r, int pair, int row0, const cplx *lds_block, f32x4 *__restrict__ Tc) {
+        const int q = tau & 3, xi = (tau >> 2) % T, quad = tau / (4 * T);
+        const int row = 4 * quad + q;
+        const f32x4 *st = reinterpret_cast<const f32x4 *>(lds_block + row * plan_region_cplx(N));
+#pragma unroll
+        for (int k = 0; k < P / 2; ++k) {
+            const int xl = xi + T * k;
+            Tc[t_unit(N, pair, r * (N / 2) + xl, row0 + row)] = st[xl];
         }
     }
 };
@@ -383,31 +414,47 @@ template <int N>
 struct Pass2 {
     static constexpr int T = plan_T(N), P = plan_P(N);
 
-    static OW_DEV void load(cplx (*d)[P], int t, int xp, const cplx *__restrict__ Tc) {
+    // a = layer 2p, b = layer 2p+1 of row x' (16 bytes per y)
+    static OW_DEV void load_pair(cplx *a, cplx *b, int t, int xp, int pair, const f32x4 *__restrict__ Tc) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const int yy = fft_in_index<N>(t, j);
-            const f32x4 *g = reinterpret_cast<const f32x4 *>(Tc + ((size_t)xp * N + yy) * kLayers);
-            const f32x4 a = g[0], b = g[1];
-            d[0][j] = cplx{a.x, a.y};
-            d[1][j] = cplx{a.z, a.w};
-            d[2][j] = cplx{b.x, b.y};
-            d[3][j] = cplx{b.z, b.w};
+            const f32x4 v = Tc[t_unit(N, pair, xp, fft_in_index<N>(t, j))];
+            a[j] = cplx{v.x, v.y};
+            b[j] = cplx{v.z, v.w};
         }
     }
 
-    // f32_row (optional): 8 pre-quantisation channels per texel [hx,hy,hz,gx,gy,dhx_dx,foam,J]
-    static OW_DEV void unpack_store(const cplx (*d)[P], int t, int xp, const CascadeFrame &cf,
-                                    u16x4 *__restrict__ disp_row, u16x4 *__restrict__ norm_row,
-                                    float *__restrict__ f32_row) {
+    // pair 0 (layers 0,1): displacement = (hx, hy, hz, 0) * sign (fft_unpack.glsl:44-50); dhy_dx is kept
+    static OW_DEV void unpack_displacement(const cplx *l0, const cplx *l1, float *dhy_dx, int t, int xp,
+                                           u16x4 *__restrict__ disp_row, float *__restrict__ f32_row) {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
             const int yp = t + T * o;
             const int sl = OutMap<N>::slot_of(o);
             const float sgn = ((xp ^ yp) & 1) ? -1.0f : 1.0f;  // fft_unpack.glsl:38
-            const float hx = d[0][sl].x * sgn, hy = d[0][sl].y * sgn, hz = d[1][sl].x * sgn;
-            const float dhy_dx = d[1][sl].y * sgn, dhy_dz = d[2][sl].x * sgn, dhx_dx = d[2][sl].y * sgn;
-            const float dhz_dz = d[3][sl].x * sgn, dhz_dx = d[3][sl].y * sgn;
+            const float hx = l0[sl].x * sgn, hy = l0[sl].y * sgn, hz = l1[sl].x * sgn;
+            dhy_dx[o] = l1[sl].y * sgn;
+            disp_row[yp] = u16x4{f2h(hx), f2h(hy), f2h(hz), f2h(0.0f * sgn)};
+            if (f32_row) {
+                float *q = f32_row + (size_t)yp * 8;
+                q[0] = hx;
+                q[1] = hy;
+                q[2] = hz;
+            }
+        }
+    }
+
+    // pair 1 (layers 2,3): Jacobian, foam RMW, normalised slopes (fft_unpack.glsl:52-67)
+    // f32_row (optional): 8 pre-quantisation channels per texel [hx,hy,hz,gx,gy,dhx_dx,foam,J]
+    static OW_DEV void unpack_normal(const cplx *l2, const cplx *l3, const float *dhy_dx, int t, int xp,
+                                     const CascadeFrame &cf, u16x4 *__restrict__ norm_row, float *__restrict__ f32_row) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int yp = t + T * o;
+            const int sl = OutMap<N>::slot_of(o);
+            const float sgn = ((xp ^ yp) & 1) ? -1.0f : 1.0f;
+            const float dhy_dz = l2[sl].x * sgn, dhx_dx = l2[sl].y * sgn;
+            const float dhz_dz = l3[sl].x * sgn, dhz_dx = l3[sl].y * sgn;
 
             const float jac = (1.0f + dhx_dx) * (1.0f + dhz_dz) - dhz_dx * dhz_dx;
             const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
@@ -415,15 +462,17 @@ struct Pass2 {
             foam = mul_rn(foam, cf.foam_decay);
             foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
             foam = fminf(fmaxf(foam, 0.0f), 1.0f);
-            const float gx = dhy_dx / (1.0f + fabsf(dhx_dx));
+            const float gx = dhy_dx[o] / (1.0f + fabsf(dhx_dx));
             const float gy = dhy_dz / (1.0f + fabsf(dhz_dz));
 
-            disp_row[yp] = u16x4{f2h(hx), f2h(hy), f2h(hz), f2h(0.0f * sgn)};
             norm_row[yp] = u16x4{f2h(gx), f2h(gy), f2h(dhx_dx), f2h(foam)};
             if (f32_row) {
-                f32x4 *q = reinterpret_cast<f32x4 *>(f32_row + (size_t)yp * 8);
-                q[0] = f32x4{hx, hy, hz, gx};
-                q[1] = f32x4{gy, dhx_dx, foam, jac};
+                float *q = f32_row + (size_t)yp * 8;
+                q[3] = gx;
+                q[4] = gy;
+                q[5] = dhx_dx;
+                q[6] = foam;
+                q[7] = jac;
             }
         }
     }

@@ -13,24 +13,26 @@ using namespace ow;
 
 namespace {
 
-template <int N>
-struct Wave {
-    static constexpr int Tn = plan_T(N), P = plan_P(N), RW = plan_rows_per_wave(N);
-    std::vector<cplx> lds = std::vector<cplx>(plan_lds_cplx(N));
+// a block of NT threads; row of thread tau = tau / T; each row has its own LDS region (plan_region_cplx)
+template <int N, int NT>
+struct Block {
+    static constexpr int Tn = plan_T(N), P = plan_P(N);
+    std::vector<cplx> lds = std::vector<cplx>(plan_region_cplx(N) * (NT / Tn));
     std::vector<cplx> tw;
-    Wave() { fill_twiddles<N>(tw); }
+    Block() { fill_twiddles<N>(tw); }
+    cplx *row(int tau) { return lds.data() + (tau / Tn) * plan_region_cplx(N); }
 
-    // row IFFT of layer data d[lane][P] for all 64 lanes in lockstep (mirrors row_ifft<N> in ow_frame.hip)
+    // row IFFT of d[tau][P] for all threads in lockstep (mirrors row_ifft<N> in ow_frame_kernels.h;
+    // every loop below is one phase between two wave_sync()s)
     void row_ifft(cplx (*d)[P]) {
-        auto row = [&](int lane) { return lds.data() + (lane / Tn) * plan_row_slots(N); };
-        for (int l = 0; l < 64; ++l) { fft_stage_compute<N, 0>(d[l], l % Tn, tw.data()); }
-        for (int l = 0; l < 64; ++l) { fft_stage_write<N, 0>(d[l], l % Tn, row(l)); }
-        for (int l = 0; l < 64; ++l) { fft_stage_read<N, 1>(d[l], l % Tn, row(l)); }
-        for (int l = 0; l < 64; ++l) { fft_stage_compute<N, 1>(d[l], l % Tn, tw.data()); }
+        for (int l = 0; l < NT; ++l) fft_stage_compute<N, 0>(d[l], l % Tn, tw.data());
+        for (int l = 0; l < NT; ++l) fft_stage_write<N, 0>(d[l], l % Tn, row(l));
+        for (int l = 0; l < NT; ++l) fft_stage_read<N, 1>(d[l], l % Tn, row(l));
+        for (int l = 0; l < NT; ++l) fft_stage_compute<N, 1>(d[l], l % Tn, tw.data());
         if constexpr (plan_S(N) == 3) {
-            for (int l = 0; l < 64; ++l) { fft_stage_write<N, 1>(d[l], l % Tn, row(l)); }
-            for (int l = 0; l < 64; ++l) { fft_stage_read<N, 2>(d[l], l % Tn, row(l)); }
-            for (int l = 0; l < 64; ++l) { fft_stage_compute<N, 2>(d[l], l % Tn, tw.data()); }
+            for (int l = 0; l < NT; ++l) fft_stage_write<N, 1>(d[l], l % Tn, row(l));
+            for (int l = 0; l < NT; ++l) fft_stage_read<N, 2>(d[l], l % Tn, row(l));
+            for (int l = 0; l < NT; ++l) fft_stage_compute<N, 2>(d[l], l % Tn, tw.data());
         }
     }
 };
@@ -38,7 +40,7 @@ struct Wave {
 template <int N>
 void rows_fft(const float *in, float *out, int rows) {
     constexpr int Tn = plan_T(N), P = plan_P(N), RW = plan_rows_per_wave(N);
-    Wave<N> w;
+    Block<N, 64> w;
     static cplx d[64][P];
     for (int r0 = 0; r0 < rows; r0 += RW) {
         for (int l = 0; l < 64; ++l) {
@@ -63,41 +65,63 @@ void rows_fft(const float *in, float *out, int rows) {
 template <int N>
 void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, float *f32) {
     constexpr int Tn = plan_T(N), P = plan_P(N), RW = plan_rows_per_wave(N);
-    Wave<N> w;
-    static cplx h[64][P], out[64][kLayers][P], tmp[64][P];
+    constexpr int NT1 = 64 * plan_p1_waves(N), ROWS1 = plan_p1_rows(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    f32x4 *Tc = reinterpret_cast<f32x4 *>(Tbuf);
     // ---- pass 1 (mirrors k_pass1) ----
-    for (int row0 = 0; row0 < N; row0 += RW) {
-        for (int l = 0; l < 64; ++l) {
-            const int y = row0 + l / Tn;
-            Pass1<N>::load_modulate(h[l], l % Tn, reinterpret_cast<const f32x4 *>(h0) + (size_t)y * N, omega + (size_t)y * N, cf.time);
-        }
-        for (int L = 0; L < kLayers; ++L) {
-            for (int l = 0; l < 64; ++l) {
-                const int y = row0 + l / Tn, t = l % Tn;
-                const float ky = (float)(y - N / 2) * dky;
-                if (L == 0) Pass1<N>::template layer_input<0>(tmp[l], h[l], t, ky, dkx);
-                if (L == 1) Pass1<N>::template layer_input<1>(tmp[l], h[l], t, ky, dkx);
-                if (L == 2) Pass1<N>::template layer_input<2>(tmp[l], h[l], t, ky, dkx);
-                if (L == 3) Pass1<N>::template layer_input<3>(tmp[l], h[l], t, ky, dkx);
+    {
+        Block<N, NT1> w;
+        static cplx h[NT1][P], a[NT1][P], b[NT1][P];
+        for (int row0 = 0; row0 < N; row0 += ROWS1) {
+            for (int l = 0; l < NT1; ++l) {
+                const int y = row0 + l / Tn;
+                Pass1<N>::load_modulate(h[l], l % Tn, reinterpret_cast<const f32x4 *>(h0) + (size_t)y * N, omega + (size_t)y * N, cf.time);
             }
-            w.row_ifft(tmp);
-            for (int l = 0; l < 64; ++l) std::memcpy(out[l][L], tmp[l], sizeof(tmp[l]));
+            for (int pair = 0; pair < 2; ++pair) {
+                for (int l = 0; l < NT1; ++l) {
+                    const int y = row0 + l / Tn, t = l % Tn;
+                    const float ky = (float)(y - N / 2) * dky;
+                    if (pair == 0) {
+                        Pass1<N>::template layer_input<0>(a[l], h[l], t, ky, dkx);
+                        Pass1<N>::template layer_input<1>(b[l], h[l], t, ky, dkx);
+                    } else {
+                        Pass1<N>::template layer_input<2>(a[l], h[l], t, ky, dkx);
+                        Pass1<N>::template layer_input<3>(b[l], h[l], t, ky, dkx);
+                    }
+                }
+                w.row_ifft(a);
+                w.row_ifft(b);
+                for (int r = 0; r < 2; ++r) {
+                    for (int l = 0; l < NT1; ++l) Pass1<N>::stage_write(a[l], b[l], l % Tn, r, w.row(l));
+                    // __syncthreads()
+                    for (int l = 0; l < NT1; ++l) Pass1<N>::stage_store(l, r, pair, row0, w.lds.data(), Tc);
+                    // __syncthreads()
+                }
+            }
         }
-        for (int l = 0; l < 64; ++l) Pass1<N>::store(out[l], l % Tn, row0 + l / Tn, reinterpret_cast<cplx *>(Tbuf));
     }
     // ---- pass 2 (mirrors k_pass2) ----
-    for (int row0 = 0; row0 < N; row0 += RW) {
-        for (int l = 0; l < 64; ++l) Pass2<N>::load(out[l], l % Tn, row0 + l / Tn, reinterpret_cast<const cplx *>(Tbuf));
-        for (int L = 0; L < kLayers; ++L) {
-            for (int l = 0; l < 64; ++l) std::memcpy(tmp[l], out[l][L], sizeof(tmp[l]));
-            w.row_ifft(tmp);
-            for (int l = 0; l < 64; ++l) std::memcpy(out[l][L], tmp[l], sizeof(tmp[l]));
-        }
-        for (int l = 0; l < 64; ++l) {
-            const int xp = row0 + l / Tn;
-            Pass2<N>::unpack_store(out[l], l % Tn, xp, cf, reinterpret_cast<u16x4 *>(disp) + (size_t)xp * N,
-                                   reinterpret_cast<u16x4 *>(norm) + (size_t)xp * N, f32 ? f32 + (size_t)xp * N * 8 : nullptr);
+    {
+        Block<N, 64> w;
+        static cplx a[64][P], b[64][P];
+        static float dhy_dx[64][P];
+        for (int row0 = 0; row0 < N; row0 += RW) {
+            for (int l = 0; l < 64; ++l) Pass2<N>::load_pair(a[l], b[l], l % Tn, row0 + l / Tn, 0, Tc);
+            w.row_ifft(a);
+            w.row_ifft(b);
+            for (int l = 0; l < 64; ++l) {
+                const int xp = row0 + l / Tn;
+                Pass2<N>::unpack_displacement(a[l], b[l], dhy_dx[l], l % Tn, xp, reinterpret_cast<u16x4 *>(disp) + (size_t)xp * N,
+                                              f32 ? f32 + (size_t)xp * N * 8 : nullptr);
+            }
+            for (int l = 0; l < 64; ++l) Pass2<N>::load_pair(a[l], b[l], l % Tn, row0 + l / Tn, 1, Tc);
+            w.row_ifft(a);
+            w.row_ifft(b);
+            for (int l = 0; l < 64; ++l) {
+                const int xp = row0 + l / Tn;
+                Pass2<N>::unpack_normal(a[l], b[l], dhy_dx[l], l % Tn, xp, cf, reinterpret_cast<u16x4 *>(norm) + (size_t)xp * N,
+                                        f32 ? f32 + (size_t)xp * N * 8 : nullptr);
+            }
         }
     }
 }
@@ -127,7 +151,7 @@ void emul_spectrum(int n, const SpectrumPC *pc, float *h0, float *omega) {
         }
 }
 
-// one frame of one cascade: Tbuf = 4*n*n*2 floats (layout [x'][y][layer]), norm is read (foam) and rewritten
+// one frame of one cascade: Tbuf = 4*n*n*2 floats (device layout, see t_unit), norm is read (foam) and rewritten
 int emul_frame(int n, const float *h0, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
                uint16_t *norm, float *f32) {
     switch (n) {

@@ -18,8 +18,9 @@ TOL_FOAM_ABS = 2.0 ** -10
 
 def relmax(a, b):
     """max|a-b| / max|b| (max-norm relative error)"""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
+    a, b = np.asarray(a), np.asarray(b)
+    kind = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = a.astype(kind), b.astype(kind)
     den = np.abs(b).max()
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
 

@@ -1,0 +1,97 @@
+"""CPU emulation of the lane-level device code (godotoceanwaves_amd/csrc/ow_device.h compiled as plain
+C++, 64 lanes stepped phase by phase) against NumPy and the oracle.  Guards the index math, twiddles,
+layouts and orientation of the HIP kernels on a machine without a GPU.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd.presets import DEPTH, UPDATE_DELTA, cascade_preset
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "godotoceanwaves_amd", "csrc")
+
+
+class PC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("seed_x", "seed_y")] + \
+               [(n, C.c_float) for n in ("tile_x", "tile_y", "alpha", "peak_frequency", "wind_speed", "angle", "depth", "swell", "detail", "spread")]
+
+
+class CF(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("tile_x", "tile_y", "time", "whitecap", "foam_grow_rate", "foam_decay")] + \
+               [("cascade", C.c_int32), ("pad0", C.c_int32)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(HERE, "emul", "libemul.so")
+    srcs = [os.path.join(HERE, "emul", "emul.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                        "-I", CSRC, srcs[0], "-o", so], check=True)
+    E = C.CDLL(so)
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
+    E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
+    E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p]
+    E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, f32p]
+    E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
+    return E
+
+
+def test_sincos_phase_accuracy(emul):
+    """phase arguments up to 2e4 rad (omega ~ 70 rad/s x t ~ 160 s): |err| <= 1.2e-7 (about 1 ulp at 1.0)"""
+    rng = np.random.default_rng(1)
+    ph = (rng.random(400000) * 2e4).astype(np.float32)
+    sn, cs = np.zeros_like(ph), np.zeros_like(ph)
+    emul.emul_sincos(len(ph), ph, sn, cs)
+    assert np.abs(sn - np.sin(ph.astype(np.float64))).max() < 1.2e-7
+    assert np.abs(cs - np.cos(ph.astype(np.float64))).max() < 1.2e-7
+
+
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048])
+def test_row_ifft_is_unnormalised_inverse_dft(emul, n):
+    """fft_compute.glsl row pass == N * ifft; asymmetric random input catches index swaps"""
+    rng = np.random.default_rng(n)
+    rows = 8
+    x = rng.standard_normal((rows, n, 2)).astype(np.float32)
+    y = np.zeros_like(x)
+    assert emul.emul_rows_fft(n, x, y, rows) == 0
+    ref = np.fft.ifft(x[..., 0].astype(np.float64) + 1j * x[..., 1], axis=1) * n
+    assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 5e-7
+
+
+@pytest.mark.parametrize("n,ci", [(128, 0), (256, 2), (512, 1)])
+def test_emulated_kernels_match_oracle(emul, n, ci):
+    p = cascade_preset(ci)
+    pc = H.spectrum_pc(p)
+    epc = PC(p["spectrum_seed"][0], p["spectrum_seed"][1], p["tile_length"][0], p["tile_length"][1], pc.alpha, pc.peak_frequency,
+             pc.wind_speed, pc.angle, DEPTH, p["swell"], p["detail"], p["spread"])
+    h0, om = np.zeros((n, n, 4), np.float32), np.zeros((n, n), np.float32)
+    emul.emul_spectrum(n, C.byref(epc), h0, om)
+    # same libm on both sides + contraction off => the one-time spectrum and omega are BIT-identical
+    assert np.array_equal(h0, O.spectrum_compute(n, pc))
+    assert np.array_equal(om, O.omega(n, p["tile_length"], DEPTH))
+
+    g = H.oracle_generator(n, [ci])
+    norm = np.zeros((n, n, 4), np.uint16)
+    for frame in range(3):
+        g.update_all(UPDATE_DELTA)
+        P = g.params[0]
+        cf = CF(p["tile_length"][0], p["tile_length"][1], np.float32(P.time), p["whitecap"], np.float32(P.foam_grow_rate),
+                np.exp(-np.float32(P.foam_decay_rate), dtype=np.float32), 0, 0)
+        T = np.zeros((n * n * 4 * 2,), np.float32)
+        disp, f32 = np.zeros((n, n, 4), np.uint16), np.zeros((n, n, 8), np.float32)
+        assert emul.emul_frame(n, h0, om, C.byref(cf), T, disp, norm, f32) == 0
+        ref = g.f32(0)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < 5e-6, (frame, name)
+        assert H.fp16_close(disp, g.displacement(0)) <= 1.0
+        assert H.fp16_close(norm[..., :3], g.normal(0)[..., :3]) <= 1.0

@@ -1,0 +1,74 @@
+// kbench.hip -- developer microbenchmark (not part of the product): ablation variants of the frame
+// kernels + per-wave timestamps, timed with hipEvents.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
+//   -I godotoceanwaves_amd/csrc tools/kbench.hip -o tools/kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "ow_frame_kernels.h"
+#include "ow_tables.h"
+
+using namespace ow;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <class F>
+float time_it(F f, int iters, hipStream_t s) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
+int main(int argc, char **argv) {
+    constexpr int N = 1024;
+    const int C = argc > 1 ? atoi(argv[1]) : 4;
+    const size_t pl = (size_t)N * N, L = C;
+    DeviceBuffers buf{};
+    CK(hipMalloc(&buf.h0, L * pl * 16)); CK(hipMalloc(&buf.omega, L * pl * 4)); CK(hipMalloc((void**)&buf.T, L * pl * 32));
+    CK(hipMalloc(&buf.disp, L * pl * 8)); CK(hipMalloc(&buf.norm, L * pl * 8));
+    std::vector<float> hh(L * pl * 4); for (size_t i = 0; i < hh.size(); ++i) hh[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.5f;
+    CK(hipMemcpy(buf.h0, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> om(L * pl); for (size_t i = 0; i < om.size(); ++i) om[i] = (float)(i % 9973) * 0.005f;
+    CK(hipMemcpy(buf.omega, om.data(), om.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(buf.norm, 0, L * pl * 8)); CK(hipMemset(buf.T, 0, L * pl * 32));
+    std::vector<cplx> tw; make_twiddles(N, tw); cplx *twd; CK(hipMalloc(&twd, tw.size() * 8)); CK(hipMemcpy(twd, tw.data(), tw.size() * 8, hipMemcpyHostToDevice)); buf.tw = twd;
+    FrameArgs args{}; for (int i = 0; i < C; ++i) { args.c[i] = CascadeFrame{88.f + i, 88.f + i, 120.5f + i, 0.5f, 0.75f, 0.9f, i, 0}; }
+    Stamp *st; CK(hipMalloc(&st, sizeof(Stamp) * C * N));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const int blocks1 = C * (N / plan_p1_rows(N)), blocks2 = C * N; const int thr1 = 64 * plan_p1_waves(N);
+    DebugArgs dbg{st, 0, 0};
+    const int iters = 30;
+#define RUN1(VAR) printf("pass1 var %2d : %8.2f us\n", VAR, time_it([&] { hipLaunchKernelGGL((k_pass1<N, VAR>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg); }, iters, s));
+#define RUN2(VAR) printf("pass2 var %2d : %8.2f us\n", VAR, time_it([&] { hipLaunchKernelGGL((k_pass2<N, false, VAR>), dim3(blocks2), dim3(64), 0, s, buf, args, dbg); }, iters, s));
+    RUN1(0) RUN1(1) RUN1(2) RUN1(3) RUN1(4) RUN1(5) RUN1(6) RUN1(7)
+    RUN2(0) RUN2(1) RUN2(2) RUN2(3) RUN2(4) RUN2(5) RUN2(6) RUN2(7)
+    // both passes back to back (a tick)
+    printf("tick        : %8.2f us\n", time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
+                                                      hipLaunchKernelGGL((k_pass2<N, false, 0>), dim3(blocks2), dim3(64), 0, s, buf, args, dbg); }, iters, s));
+    // timestamps
+    for (int pass = 1; pass <= 2; ++pass) {
+        if (pass == 1) hipLaunchKernelGGL((k_pass1<N, 8>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
+        else hipLaunchKernelGGL((k_pass2<N, false, 8>), dim3(blocks2), dim3(64), 0, s, buf, args, dbg);
+        CK(hipStreamSynchronize(s));
+        const int blocks = C * N; std::vector<Stamp> h(blocks); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * blocks, hipMemcpyDeviceToHost));
+        unsigned long long tmin = ~0ull; for (auto &x : h) tmin = std::min(tmin, x.t[0]);
+        // wall_clock64 ticks at 100 MHz -> 10 ns
+        double avg[5] = {0}; for (auto &x : h) for (int k = 0; k < 5; ++k) avg[k] += (double)(x.t[k] - tmin) * 0.01 / blocks;
+        printf("pass%d stamps (us, avg over waves): start %.1f  loaded %.1f  half %.1f  fftdone %.1f  stored %.1f\n", pass, avg[0], avg[1], avg[2], avg[3], avg[4]);
+        // distribution of start times and xcc mapping
+        int xccmap[8] = {0}; int agree = 0; for (int b = 0; b < blocks; ++b) { xccmap[h[b].xcc & 7]++; agree += ((int)(h[b].xcc & 7) == b % 8); }
+        printf("  xcc == block%%8 for %d of %d blocks; per-xcc counts:", agree, blocks); for (int i = 0; i < 8; ++i) printf(" %d", xccmap[i]); printf("\n");
+        std::vector<double> starts; for (auto &x : h) starts.push_back((double)(x.t[0] - tmin) * 0.01); std::sort(starts.begin(), starts.end());
+        printf("  start-time percentiles us: p10 %.1f p50 %.1f p90 %.1f max %.1f ; durations: ", starts[blocks / 10], starts[blocks / 2], starts[blocks * 9 / 10], starts.back());
+        std::vector<double> dur; for (auto &x : h) dur.push_back((double)(x.t[4] - x.t[0]) * 0.01); std::sort(dur.begin(), dur.end());
+        printf("p10 %.1f p50 %.1f p90 %.1f\n", dur[blocks / 10], dur[blocks / 2], dur[blocks * 9 / 10]);
+        double seg[4] = {0}; for (auto &x : h) for (int k = 0; k < 4; ++k) seg[k] += (double)(x.t[k + 1] - x.t[k]) * 0.01 / blocks;
+        printf("  avg segment us: load+modulate %.2f | layers01 %.2f | layers23 %.2f | store %.2f\n", seg[0], seg[1], seg[2], seg[3]);
+    }
+    return 0;
+}
