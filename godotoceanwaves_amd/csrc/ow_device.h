@@ -21,17 +21,26 @@
 #define OW_DEV __device__ __forceinline__
 #define OW_HD __host__ __device__ __forceinline__
 #define OW_DEVICE_BUILD 1
+// scheduling fence for the compiler only (no instruction): keeps live ranges short where it matters
+#define OW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define OW_DEV inline
 #define OW_HD inline
 #define OW_DEVICE_BUILD 0
+#define OW_SCHED_FENCE() ((void)0)
 #endif
 
 namespace ow {
 
+#if OW_DEVICE_BUILD
+// two adjacent VGPRs: complex add / sub / scale map onto the packed FP32 instructions (v_pk_add_f32, v_pk_mul_f32,
+// v_pk_fma_f32 with op_sel / neg modifiers) without register shuffling
+typedef float cplx __attribute__((ext_vector_type(2)));
+#else
 struct alignas(8) cplx {
     float x, y;
 };
+#endif
 struct alignas(16) f32x4 {
     float x, y, z, w;
 };
@@ -44,32 +53,33 @@ constexpr float kG = 9.81f;                // GLSL `#define G`
 constexpr int kLayers = 4;                 // NUM_SPECTRA (spectrum_modulate.glsl:14)
 
 // ------------------------------------------------------------------------------------
-// FFT plan (compile time).  N = 16 * T' ; T = lanes per row ; P = points per lane.
+// FFT plan (compile time).  P = 16 points per lane for every size; T = N/16 lanes cooperate on a row
+// (T = 128 at N = 2048: the row's exchanges then cross two waves and use the workgroup barrier).
 // ------------------------------------------------------------------------------------
-constexpr int plan_T(int N) { return N >= 1024 ? 64 : N / 16; }
-constexpr int plan_P(int N) { return N / plan_T(N); }
+constexpr int kP = 16;
+constexpr int plan_T(int N) { return N / kP; }
+constexpr int plan_P(int) { return kP; }
 constexpr int plan_S(int N) { return N <= 256 ? 2 : 3; }
 constexpr int plan_R(int N, int j) { return j == 0 ? 16 : (j == 1 ? (N == 128 ? 8 : 16) : N / 256); }
-constexpr int plan_s(int N, int j) { return j == 0 ? 1 : plan_s(N, j - 1) * plan_R(N, j - 1); }  // stride
+constexpr int plan_s(int N, int j) { return j == 0 ? 1 : (j == 1 ? 16 : 16 * plan_R(N, 1)); }  // stride = product of earlier radices (no recursion: must fold)
 constexpr int plan_n(int N, int j) { return N / plan_s(N, j); }                                 // sub-length
 constexpr int plan_m(int N, int j) { return plan_n(N, j) / plan_R(N, j); }
 constexpr int plan_B(int N, int j) { return (N / plan_R(N, j)) / plan_T(N); }  // butterflies per lane
-constexpr int plan_rows_per_wave(int N) { return 64 / plan_T(N); }
-// pass 1 workgroup: as many waves as it takes to cover 4 consecutive rows (the row quad that forms one
-// contiguous run of the transposed intermediate)
-constexpr int plan_p1_waves(int N) { return plan_rows_per_wave(N) >= 4 ? 1 : 4 / plan_rows_per_wave(N); }
-constexpr int plan_p1_rows(int N) { return plan_p1_waves(N) * plan_rows_per_wave(N); }
-// LDS row region: FFT exchange image (N + N/16 complex) or staging image (N/2 float4), + 64 B so that the
-// four row regions of a quad start on different 16-byte bank slots
-constexpr int plan_region_cplx(int N) { return N + N / 16 + 8; }
+// workgroup = the lanes of 8 consecutive rows.  Pass 1: each x' gets one full 64-byte write request of the
+// transposed intermediate; both passes: the 8 rows share one LDS copy of the twiddle table.
+constexpr int kWgRows = 8;
+constexpr int plan_wg_threads(int N) { return kWgRows * plan_T(N); }
+constexpr bool plan_row_spans_waves(int N) { return plan_T(N) > 64; }
+// LDS row region: FFT exchange image (N + N/16 complex, padded slots) or staging image (N complex, linear),
+// + 32 B so that the 8 row regions of a block start 8 banks apart (conflict-free transposed reads)
+constexpr int plan_region_cplx(int N) { return N + N / 16 + 4; }
 // twiddle table: for every non-last stage j a [R_j - 1][m_j] block of exp(+2*pi*i*p*k/n_j)
 constexpr int plan_tw_size(int N, int j) { return (plan_R(N, j) - 1) * plan_m(N, j); }
-constexpr int plan_tw_off(int N, int j) { return j == 0 ? 0 : plan_tw_off(N, j - 1) + plan_tw_size(N, j - 1); }
+constexpr int plan_tw_off(int N, int j) { return j == 0 ? 0 : (j == 1 ? plan_tw_size(N, 0) : plan_tw_size(N, 0) + plan_tw_size(N, 1)); }
 constexpr int plan_tw_total(int N) { return plan_tw_off(N, plan_S(N) - 1); }
-// LDS: one padded row buffer per row carried by the wave
 constexpr int lds_slot(int e) { return e + (e >> 4); }
-constexpr int plan_row_slots(int N) { return N + N / 16; }
-constexpr int plan_lds_cplx(int N) { return plan_region_cplx(N) * plan_rows_per_wave(N); }
+// whole workgroup: [twiddle table][8 x row region]
+constexpr int plan_wg_lds_cplx(int N) { return plan_region_cplx(N) * kWgRows + plan_tw_total(N); }
 
 // register slot that holds output k of an in-place radix-R butterfly (see dft<R>)
 constexpr int dft_pos(int R, int k) { return R == 16 ? 4 * (k % 4) + k / 4 : (R == 8 ? 2 * (k % 4) + k / 4 : k); }
@@ -77,10 +87,19 @@ constexpr int dft_pos(int R, int k) { return R == 16 ? 4 * (k % 4) + k / 4 : (R 
 // ------------------------------------------------------------------------------------
 // complex helpers
 // ------------------------------------------------------------------------------------
-OW_DEV cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+#if OW_DEVICE_BUILD
+OW_DEV cplx cadd(cplx a, cplx b) { return a + b; }
+OW_DEV cplx csub(cplx a, cplx b) { return a - b; }
+OW_DEV cplx cmuli(cplx a) { return cplx{-a.y, a.x}; }  // i * a
+OW_DEV cplx cmul(cplx a, cplx b) { return a.xx * b + a.yy * cplx{-b.y, b.x}; }
+OW_DEV cplx cscale(cplx a, float s) { return a * s; }
+#else
 OW_DEV cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
 OW_DEV cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
 OW_DEV cplx cmuli(cplx a) { return cplx{-a.y, a.x}; }  // i * a
+OW_DEV cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+OW_DEV cplx cscale(cplx a, float s) { return cplx{a.x * s, a.y * s}; }
+#endif
 
 // Inverse-sign (e^{+2*pi*i/R}) radix butterflies, in place.
 OW_DEV void dft2(cplx &a, cplx &b) {
@@ -95,6 +114,9 @@ OW_DEV void dft4(cplx &a, cplx &b, cplx &c, cplx &d) {
     c = csub(t0, t2);
     d = csub(t1, t3);
 }
+// a * (1 + i) / sqrt(2), a * (-1 + i) / sqrt(2)
+OW_DEV cplx cmul_w8_1(cplx a) { return cscale(cadd(a, cmuli(a)), 0.70710678118654752f); }
+OW_DEV cplx cmul_w8_3(cplx a) { return cscale(csub(cmuli(a), a), 0.70710678118654752f); }
 
 template <int R>
 struct Dft;
@@ -110,12 +132,11 @@ template <>
 struct Dft<8> {
     // n = 2*n1 + n2, k = k1 + 4*k2 : W8^{nk} = W4^{n1 k1} * W8^{n2 k1} * W2^{n2 k2}; output k at slot 2*k1 + k2
     static OW_DEV void run(cplx *v) {
-        const float h = 0.70710678118654752f;
         dft4(v[0], v[2], v[4], v[6]);
         dft4(v[1], v[3], v[5], v[7]);
-        v[3] = cplx{(v[3].x - v[3].y) * h, (v[3].x + v[3].y) * h};   // * W8^1
-        v[5] = cmuli(v[5]);                                          // * W8^2
-        v[7] = cplx{(-v[7].x - v[7].y) * h, (v[7].x - v[7].y) * h};  // * W8^3
+        v[3] = cmul_w8_1(v[3]);  // * W8^1
+        v[5] = cmuli(v[5]);      // * W8^2
+        v[7] = cmul_w8_3(v[7]);  // * W8^3
         dft2(v[0], v[1]);
         dft2(v[2], v[3]);
         dft2(v[4], v[5]);
@@ -125,26 +146,32 @@ struct Dft<8> {
 template <>
 struct Dft<16> {
     // n = 4*n1 + n2, k = k1 + 4*k2 : W16^{nk} = W4^{n1 k1} * W16^{n2 k1} * W4^{n2 k2}; output k at slot 4*k1 + k2
+    // (scheduling fences keep at most two radix-4 butterflies' temporaries alive at a time)
     static OW_DEV void run(cplx *v) {
-        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
         dft4(v[0], v[4], v[8], v[12]);
         dft4(v[1], v[5], v[9], v[13]);
+        OW_SCHED_FENCE();
         dft4(v[2], v[6], v[10], v[14]);
         dft4(v[3], v[7], v[11], v[15]);
+        OW_SCHED_FENCE();
         // slot 4*k1 + n2 holds u[n2][k1]; multiply by W16^{n2*k1}
-        v[5] = cmul(v[5], cplx{c1, s1});                                 // W16^1
-        v[6] = cplx{(v[6].x - v[6].y) * h, (v[6].x + v[6].y) * h};       // W16^2
-        v[7] = cmul(v[7], cplx{s1, c1});                                 // W16^3
-        v[9] = cplx{(v[9].x - v[9].y) * h, (v[9].x + v[9].y) * h};       // W16^2
-        v[10] = cmuli(v[10]);                                            // W16^4
-        v[11] = cplx{(-v[11].x - v[11].y) * h, (v[11].x - v[11].y) * h}; // W16^6
-        v[13] = cmul(v[13], cplx{s1, c1});                               // W16^3
-        v[14] = cplx{(-v[14].x - v[14].y) * h, (v[14].x - v[14].y) * h}; // W16^6
-        v[15] = cmul(v[15], cplx{-c1, -s1});                             // W16^9
+        v[5] = cmul(v[5], cplx{c1, s1});           // W16^1
+        v[6] = cmul_w8_1(v[6]);                    // W16^2
+        v[7] = cmul(v[7], cplx{s1, c1});           // W16^3
+        v[9] = cmul_w8_1(v[9]);                    // W16^2
+        v[10] = cmuli(v[10]);                      // W16^4
+        v[11] = cmul_w8_3(v[11]);                  // W16^6
+        v[13] = cmul(v[13], cplx{s1, c1});         // W16^3
+        v[14] = cmul_w8_3(v[14]);                  // W16^6
+        v[15] = cmul(v[15], cplx{-c1, -s1});       // W16^9
+        OW_SCHED_FENCE();
         dft4(v[0], v[1], v[2], v[3]);
         dft4(v[4], v[5], v[6], v[7]);
+        OW_SCHED_FENCE();
         dft4(v[8], v[9], v[10], v[11]);
         dft4(v[12], v[13], v[14], v[15]);
+        OW_SCHED_FENCE();
     }
 };
 
@@ -159,46 +186,72 @@ OW_DEV void fft_stage_compute(cplx *d, int t, const cplx *__restrict__ tw) {
     constexpr int R = plan_R(N, J), B = plan_B(N, J), T = plan_T(N), s = plan_s(N, J), m = plan_m(N, J);
     constexpr bool last = (J == plan_S(N) - 1);
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-        Dft<R>::run(d + b * R);
-        if (!last) {
+    for (int b = 0; b < B; ++b) Dft<R>::run(d + b * R);
+    if (!last) {
+        // twiddles are fetched (LDS table) only now, when the butterfly's temporaries are dead
+        OW_SCHED_FENCE();
+        constexpr int off = plan_tw_off(N, J);
+        const cplx *twj = tw + off;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
             const int p = (t + T * b) / s;
-            const cplx *twj = tw + plan_tw_off(N, J);
 #pragma unroll
             for (int k = 1; k < R; ++k) {
                 d[b * R + dft_pos(R, k)] = cmul(d[b * R + dft_pos(R, k)], twj[(k - 1) * m + p]);
+                if (k % 5 == 0) OW_SCHED_FENCE();  // a few table reads in flight at a time, not all 15
             }
         }
+        OW_SCHED_FENCE();
     }
+}
+
+// LDS slot of the element a lane writes after / reads before a stage.  For every plan used here the slot is
+// affine in (b, k): slot(t, b, k) = slot(t, 0, 0) + [slot(0, b, k) - slot(0, 0, 0)], because T is a multiple of
+// 16 (or, at N = 128, the lane index stays below 16), so the padding term e >> 4 never carries across the lane
+// part.  The lane part is computed once per stage; the (b, k) part is a compile-time DS offset.
+template <int N, int J>
+constexpr int wr_slot(int t, int b, int k) {
+    const int R = plan_R(N, J), T = plan_T(N), s = plan_s(N, J);
+    const int u = t + T * b, q = u % s, p = u / s;
+    return lds_slot(q + s * (R * p + k));
+}
+template <int N, int J>
+constexpr int rd_slot(int t, int b, int i) {
+    const int T = plan_T(N), s = plan_s(N, J), m = plan_m(N, J);
+    const int u = t + T * b, q = u % s, p = u / s;
+    return lds_slot(q + s * (p + m * i));
 }
 
 template <int N, int J>
 OW_DEV void fft_stage_write(const cplx *d, int t, cplx *lds_row) {
-    constexpr int R = plan_R(N, J), B = plan_B(N, J), T = plan_T(N), s = plan_s(N, J);
+    constexpr int R = plan_R(N, J), B = plan_B(N, J);
+    cplx *base = lds_row + wr_slot<N, J>(t, 0, 0);
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const int u = t + T * b, q = u % s, p = u / s;
 #pragma unroll
-        for (int k = 0; k < R; ++k) lds_row[lds_slot(q + s * (R * p + k))] = d[b * R + dft_pos(R, k)];
+        for (int k = 0; k < R; ++k) base[wr_slot<N, J>(0, b, k) - wr_slot<N, J>(0, 0, 0)] = d[b * R + dft_pos(R, k)];
     }
 }
 
 template <int N, int J>
 OW_DEV void fft_stage_read(cplx *d, int t, const cplx *lds_row) {
-    constexpr int R = plan_R(N, J), B = plan_B(N, J), T = plan_T(N), s = plan_s(N, J), m = plan_m(N, J);
+    constexpr int R = plan_R(N, J), B = plan_B(N, J);
+    const cplx *base = lds_row + rd_slot<N, J>(t, 0, 0);
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const int u = t + T * b, q = u % s, p = u / s;
 #pragma unroll
-        for (int i = 0; i < R; ++i) d[b * R + i] = lds_row[lds_slot(q + s * (p + m * i))];
+        for (int i = 0; i < R; ++i) d[b * R + i] = base[rd_slot<N, J>(0, b, i) - rd_slot<N, J>(0, 0, 0)];
     }
 }
 
-// element index carried by register slot j before stage 0 / after the last stage
+// element index carried by register slot j before stage 0: t + T*j  (N/16 == T)
+template <int N>
+constexpr int fft_in_step(int j) {
+    return plan_T(N) * j;
+}
 template <int N>
 OW_DEV int fft_in_index(int t, int j) {
-    constexpr int T = plan_T(N);
-    return t + T * (j / 16) + (N / 16) * (j % 16);
+    return t + fft_in_step<N>(j);
 }
 template <int N>
 struct OutMap {
@@ -228,11 +281,39 @@ OW_DEV void sincos_phase(float ph, float &sn, float &cs) {
     cs = ((n + 1) & 2) ? -cc : cc;
 }
 
+// returns x, but the compiler cannot see that: stops it from keeping (instead of recomputing) cheap
+// per-texel terms across long code regions
+OW_DEV float opaque(float x) {
+#if OW_DEVICE_BUILD
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+// redefines c "in place" as far as the compiler can tell: nothing derived from the old value (swizzled or
+// negated copies for the packed instructions) is carried past this point
+OW_DEV void opaque_inplace(cplx &c) {
+#if OW_DEVICE_BUILD
+    asm volatile("" : "+v"(c));
+#endif
+}
+OW_DEV int opaque(int x) {
+#if OW_DEVICE_BUILD
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 OW_DEV float fast_rcp(float x) {
 #if OW_DEVICE_BUILD
     return __builtin_amdgcn_rcpf(x);
 #else
     return 1.0f / x;
+#endif
+}
+OW_DEV float fast_rsq(float x) {
+#if OW_DEVICE_BUILD
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
 #endif
 }
 OW_DEV float fast_sqrt(float x) {
@@ -315,14 +396,81 @@ struct FrameArgs {
     CascadeFrame c[kMaxCascades];
 };
 
-// Intermediate layout (device-private): two planes, one per packed layer PAIR p = layer/2,
-//   T[c][p][y/8][x'][y%8] of float4 = (layer 2p, layer 2p+1) complex FP32   (16-byte units).
-// One 128-byte line = 8 consecutive y of one x'.  Pass 1 stages a pair through LDS and every wave
-// store instruction writes 16 x' x (4 rows x 16 B = one full 64-byte write request); pass 2 lane octets
-// read whole 128-byte lines.
-OW_HD size_t t_unit(int n, int pair, int xp, int y) {  // index in f32x4 units inside one cascade
-    return ((((size_t)pair * (n >> 3) + (y >> 3)) * n + xp) << 3) + (y & 7);
+// ------------------------------------------------------------------------------------
+// Global memory access.  Every access of the frame kernels is  (wave-uniform 128-bit buffer resource)
+// + (one 32-bit per-lane byte offset) + (wave-uniform byte offset held in an SGPR): the gfx950 buffer
+// instructions take all three directly, so no 64-bit per-element address is ever formed in VGPRs.
+// The plain-C++ build (tests/emul) turns the same calls into pointer arithmetic.
+// ------------------------------------------------------------------------------------
+#if OW_DEVICE_BUILD
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+struct GBuf {
+    __amdgpu_buffer_rsrc_t r;
+};
+OW_DEV GBuf make_gbuf(const void *base, uint32_t bytes) {
+    // word 3 = 0x00020000: raw buffer, 32-bit data format (the gfx9 family default descriptor)
+    return GBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000)};
 }
+template <int AUX = 0>
+OW_DEV f32x4 gload16(GBuf b, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, AUX));
+}
+template <int AUX = 0>
+OW_DEV cplx gload8(GBuf b, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, AUX));
+}
+template <int AUX = 0>
+OW_DEV float gload4(GBuf b, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, AUX));
+}
+template <int AUX = 0>
+OW_DEV uint16_t gload2(GBuf b, uint32_t voff, uint32_t soff) {
+    return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(b.r, (int)voff, (int)soff, AUX);
+}
+template <int AUX = 0>
+OW_DEV void gstore8(GBuf b, uint32_t voff, uint32_t soff, cplx v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), b.r, (int)voff, (int)soff, AUX);
+}
+template <int AUX = 0>
+OW_DEV void gstore8h(GBuf b, uint32_t voff, uint32_t soff, u16x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), b.r, (int)voff, (int)soff, AUX);
+}
+template <int AUX = 0>
+OW_DEV void gstore16(GBuf b, uint32_t voff, uint32_t soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), b.r, (int)voff, (int)soff, AUX);
+}
+#else
+struct GBuf {
+    char *p;
+};
+OW_DEV GBuf make_gbuf(const void *base, uint32_t) { return GBuf{(char *)const_cast<void *>(base)}; }
+template <int AUX = 0>
+OW_DEV f32x4 gload16(GBuf b, uint32_t voff, uint32_t soff) { f32x4 v; __builtin_memcpy(&v, b.p + voff + soff, 16); return v; }
+template <int AUX = 0>
+OW_DEV cplx gload8(GBuf b, uint32_t voff, uint32_t soff) { cplx v; __builtin_memcpy(&v, b.p + voff + soff, 8); return v; }
+template <int AUX = 0>
+OW_DEV float gload4(GBuf b, uint32_t voff, uint32_t soff) { float v; __builtin_memcpy(&v, b.p + voff + soff, 4); return v; }
+template <int AUX = 0>
+OW_DEV uint16_t gload2(GBuf b, uint32_t voff, uint32_t soff) { uint16_t v; __builtin_memcpy(&v, b.p + voff + soff, 2); return v; }
+template <int AUX = 0>
+OW_DEV void gstore8(GBuf b, uint32_t voff, uint32_t soff, cplx v) { __builtin_memcpy(b.p + voff + soff, &v, 8); }
+template <int AUX = 0>
+OW_DEV void gstore8h(GBuf b, uint32_t voff, uint32_t soff, u16x4 v) { __builtin_memcpy(b.p + voff + soff, &v, 8); }
+template <int AUX = 0>
+OW_DEV void gstore16(GBuf b, uint32_t voff, uint32_t soff, f32x4 v) { __builtin_memcpy(b.p + voff + soff, &v, 16); }
+#endif
+// cache-policy bits of the buffer instructions (aux operand): 0 = default, 2 = nt (streamed once)
+constexpr int kAuxDefault = 0, kAuxNT = 2;
+
+// Intermediate layout (device-private), one plane per packed layer:
+//   T[c][layer][y/16][x'][y%16] complex FP32 (8-byte units); one 128-byte line = 16 consecutive y of one x'.
+// Pass 1 stages a layer through LDS and every wave store instruction writes 8 x' x (8 rows x 8 B = one full
+// 64-byte write request); pass 2 lanes read whole 128-byte lines (16 lanes x 8 B).
+OW_HD constexpr uint32_t t_unit(int n, int layer, int xp, int y) {  // index in complex units inside one cascade (< 2^24)
+    return ((((uint32_t)layer * (uint32_t)(n >> 4) + (uint32_t)(y >> 4)) * (uint32_t)n + (uint32_t)xp) << 4) + (uint32_t)(y & 15);
+}
+constexpr uint32_t t_cascade_bytes(int n) { return (uint32_t)n * (uint32_t)n * kLayers * 8u; }
 
 // k-vector component exactly as spectrum_modulate.glsl:60 writes it
 OW_DEV float modulate_kcomp(int id, int n, float tile) {
@@ -332,31 +480,36 @@ OW_DEV float modulate_kcomp(int id, int n, float tile) {
 // ------------------------------------------------------------------------------------
 // PASS 1, lane view.  Row y of cascade c: load h0 + omega, time-modulate (spectrum_modulate.glsl:64-70),
 // then for each packed layer build the row's spectrum and run the row IFFT (fft_compute.glsl, first
-// dispatch); results go to the transposed intermediate T[c][x'][y][layer].
+// dispatch); results go to the transposed intermediate T (transpose.glsl fused into the store).
 // ------------------------------------------------------------------------------------
 template <int N>
 struct Pass1 {
-    static constexpr int T = plan_T(N), P = plan_P(N);
+    static constexpr int T = plan_T(N), P = kP;
 
-    // h[j] = h(k, t) for texel x = fft_in_index(t, j)
-    static OW_DEV void load_modulate(cplx *h, int t, const f32x4 *__restrict__ h0_row,
-                                     const float *__restrict__ om_row, float time) {
+    // The ifftshift sign (-1)^(x'+y') of fft_unpack.glsl:38 is not multiplied in at the end: a factor (-1)^x' on
+    // the output of a length-N inverse DFT is a circular shift of its input by N/2, i.e. FFT slot j simply takes
+    // the texel of slot (j + 8) % 16 (N/2 = 8*T).  Pass 1 does this along x, pass 2 along y: no instruction.
+    static constexpr int rot(int j) { return (j + 8) & 15; }
+
+    // h[j] = h(k, t) = h0 * m + conj(h0(-k)) * conj(m),  m = exp(i * omega * time)   (spectrum_modulate.glsl:64-68)
+    // for the lane's texels x = t + T*rot(j) of row y; tex = y*N + t (texel index of the lane's first point)
+    static OW_DEV void load_modulate(cplx *h, uint32_t tex, GBuf h0_c, GBuf om_c, float time) {
         f32x4 v[P];
         float om[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const int x = fft_in_index<N>(t, j);
-            v[j] = h0_row[x];
-            om[j] = om_row[x];
+            v[j] = gload16(h0_c, tex * 16u, (uint32_t)(T * rot(j)) * 16u);
+            om[j] = gload4(om_c, tex * 4u, (uint32_t)(T * rot(j)) * 4u);
         }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             float sn, cs;
             sincos_phase(mul_rn(om[j], time), sn, cs);
-            // h = h0 * m + conj(h0(-k)) * conj(m),  m = (cs, sn)
             const float ar = v[j].x * cs - v[j].y * sn, ai = v[j].x * sn + v[j].y * cs;
             const float br = v[j].z * cs + v[j].w * sn, bi = v[j].w * cs - v[j].z * sn;
             h[j] = cplx{ar + br, ai + bi};
+            opaque_inplace(h[j]);
+            if (j % 4 == 3) OW_SCHED_FENCE();
         }
     }
 
@@ -367,122 +520,150 @@ struct Pass1 {
     static OW_DEV void layer_input(cplx *d, const cplx *h, int t, float ky, float dkx) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const int x = fft_in_index<N>(t, j);
+            const int x = fft_in_index<N>(t, rot(j));
             const float kx = (float)(x - N / 2) * dkx;  // not phase-amplified: 1-2 ulp from :60 is harmless
-            const float k = fast_sqrt(kx * kx + ky * ky) + 1e-6f;
-            const float ik = fast_rcp(k);
+            // 1 / (|k| + 1e-6) = rsq(k2) * (1 - 1e-6 * rsq(k2)) + O(1e-12 / k2); k2 is clamped so that the DC
+            // texel (k_vec = 0, where the reference yields k_unit = 0) stays finite
+            const float rk = fast_rsq(fmaxf(kx * kx + ky * ky, 1e-30f));
+            const float ik = rk - 1e-6f * rk * rk;
             const float ux = kx * ik, uy = ky * ik;
-            cplx cf = cplx{0.0f, 1.0f + uy};
-            if (L == 1) cf = cplx{-ky, ux};
-            if (L == 2) cf = cplx{0.0f, kx - ky * uy};
-            if (L == 3) cf = cplx{-ux * kx, -ux * ky};
-            d[j] = cmul(h[j], cf);
+            if (L == 0) {  // i (1 + uy) h
+                const float s = 1.0f + uy;
+                d[j] = cplx{-h[j].y * s, h[j].x * s};
+            }
+            if (L == 1) d[j] = cmul(h[j], cplx{-ky, ux});  // (-ky + i ux) h
+            if (L == 2) {  // i (kx - ky uy) h
+                const float s = kx - ky * uy;
+                d[j] = cplx{-h[j].y * s, h[j].x * s};
+            }
+            if (L == 3) d[j] = cmul(h[j], cplx{-ux * kx, -ux * ky});  // -ux (kx + i ky) h
+            opaque_inplace(d[j]);  // pins this texel's arithmetic here (pure ops would otherwise sink to their first use)
+            if (j % 4 == 3) OW_SCHED_FENCE();  // four texels' temporaries at a time, not sixteen
         }
     }
 
-    // Transposed store of one layer pair (a = layer 2p, b = layer 2p+1), in two rounds r = 0, 1 that each
-    // cover half of the x' range.  stage_write: every lane puts its own row's results, x'-ordered, into
-    // its row region (16 B per x').  After a workgroup barrier, stage_store: thread tau of the block takes
-    // (row q = tau % 4 of the quad, x' = tau / 4 + ...), so that consecutive lanes write consecutive
-    // 16-byte units of T.  A second barrier must follow before the regions are written again.
-    static OW_DEV void stage_write(const cplx *a, const cplx *b, int t, int r, cplx *lds_row) {
-        f32x4 *st = reinterpret_cast<f32x4 *>(lds_row);
+    // Transposed store of one layer.  stage_write: every lane puts its own row's results, x'-ordered, into
+    // its row region (8 B per x', linear).  After a workgroup (LDS) barrier, stage_store: thread tau of the
+    // block takes (row q = tau % 8, x' = tau / 8 + T*k), so that 8 consecutive lanes write the 8 consecutive
+    // 8-byte units (= 64 B) of one x'.  A second barrier must follow before the regions are written again.
+    static OW_DEV void stage_write(const cplx *d, int t, cplx *lds_row) {
 #pragma unroll
-        for (int oo = 0; oo < P / 2; ++oo) {
-            const int sl = OutMap<N>::slot_of(r * (P / 2) + oo);
-            st[t + T * oo] = f32x4{a[sl].x, a[sl].y, b[sl].x, b[sl].y};
-        }
+        for (int o = 0; o < P; ++o) lds_row[t + T * o] = d[OutMap<N>::slot_of(o)];
     }
-    // tau = thread index in the block, row0 = first map row of the block, Tc = this cascade's T
-    static OW_DEV void stage_store(int tau, int r, int pair, int row0, const cplx *lds_block, f32x4 *__restrict__ Tc) {
-        const int q = tau & 3, xi = (tau >> 2) % T, quad = tau / (4 * T);
-        const int row = 4 * quad + q;
-        const f32x4 *st = reinterpret_cast<const f32x4 *>(lds_block + row * plan_region_cplx(N));
+    // tau = thread index in the block, row0 = first map row of the block (multiple of 8), T_c = this cascade's T
+    template <int AUX>
+    static OW_DEV void stage_store(int tau, int layer, int row0, const cplx *lds_block, GBuf T_c) {
+        const int q = tau % kWgRows, xi = tau / kWgRows;  // xi in [0, T)
+        const cplx *st = lds_block + q * plan_region_cplx(N);
+        const uint32_t voff = t_unit(N, 0, xi, row0 + q) * 8u;
+        cplx v[P];
 #pragma unroll
-        for (int k = 0; k < P / 2; ++k) {
-            const int xl = xi + T * k;
-            Tc[t_unit(N, pair, r * (N / 2) + xl, row0 + row)] = st[xl];
-        }
+        for (int k = 0; k < P; ++k) v[k] = st[xi + T * k];
+#pragma unroll
+        for (int k = 0; k < P; ++k) gstore8<AUX>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * k, 0)) * 8u, v[k]);
     }
 };
 
 // ------------------------------------------------------------------------------------
-// PASS 2, lane view.  Row x' of T: load, row IFFT of the 4 layers (fft_compute.glsl, second dispatch),
-// then fft_unpack.glsl:38-68 fused: ifftshift sign, displacement, Jacobian/foam RMW, normal.
+// PASS 2, lane view.  Row x' of T: row IFFT of the 4 layers (fft_compute.glsl, second dispatch), then
+// fft_unpack.glsl:38-68 fused: ifftshift sign, displacement, Jacobian/foam RMW, normal.  The layers are
+// taken in the order 2, 3, 1, 0 so that at most two layers' worth of results wait in registers:
+//   after 2: dhy_dz, dhx_dx            after 3: Jacobian -> foam, gy  (kept as packed halves) + dhx_dx
+//   after 1: gx -> normal map store; hz kept      after 0: displacement store
 // ------------------------------------------------------------------------------------
 template <int N>
 struct Pass2 {
-    static constexpr int T = plan_T(N), P = plan_P(N);
+    static constexpr int T = plan_T(N), P = kP;
 
-    // a = layer 2p, b = layer 2p+1 of row x' (16 bytes per y)
-    static OW_DEV void load_pair(cplx *a, cplx *b, int t, int xp, int pair, const f32x4 *__restrict__ Tc) {
+    // byte offset (lane part / uniform part) of T[layer][x'][y = t + T*j] inside the cascade
+    static OW_DEV uint32_t t_voff(int t, int xp) {
+        return (T >= 16 ? t_unit(N, 0, xp, t) : t_unit(N, 0, xp, 0) + (uint32_t)t) * 8u;
+    }
+    static constexpr uint32_t t_soff(int layer, int j) {
+        return (t_unit(N, layer, 0, 0) + (T >= 16 ? t_unit(N, 0, 0, T * j) : t_unit(N, 0, 0, 16 * (j / 2)) + 8u * (j % 2))) * 8u;
+    }
+    // one packed layer of row x': d[j] = T[layer][x'][y = t + T*rot(j)]  (rot: the (-1)^y' half of the ifftshift sign,
+    // see Pass1; T already carries the (-1)^x' half)
+    static constexpr int rot(int j) { return (j + 8) & 15; }
+    template <int AUX>
+    static OW_DEV void load_layer(cplx *d, int t, int xp, int layer, GBuf T_c) {
+        const uint32_t voff = t_voff(t, xp);
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const f32x4 v = Tc[t_unit(N, pair, xp, fft_in_index<N>(t, j))];
-            a[j] = cplx{v.x, v.y};
-            b[j] = cplx{v.z, v.w};
-        }
+        for (int j = 0; j < P; ++j) d[j] = gload8<AUX>(T_c, voff, t_soff(layer, rot(j)));
+    }
+    // previous foam (FP16 bits of normal.a) of the lane's P output texels; tex = x'*N + t
+    static OW_DEV void load_foam(uint16_t *foam_prev, uint32_t tex, GBuf norm_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) foam_prev[o] = gload2(norm_c, tex * 8u + 6u, (uint32_t)(T * o) * 8u);
     }
 
-    // pair 0 (layers 0,1): displacement = (hx, hy, hz, 0) * sign (fft_unpack.glsl:44-50); dhy_dx is kept
-    static OW_DEV void unpack_displacement(const cplx *l0, const cplx *l1, float *dhy_dx, int t, int xp,
-                                           u16x4 *__restrict__ disp_row, float *__restrict__ f32_row) {
-#pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int yp = t + T * o;
-            const int sl = OutMap<N>::slot_of(o);
-            const float sgn = ((xp ^ yp) & 1) ? -1.0f : 1.0f;  // fft_unpack.glsl:38
-            const float hx = l0[sl].x * sgn, hy = l0[sl].y * sgn, hz = l1[sl].x * sgn;
-            dhy_dx[o] = l1[sl].y * sgn;
-            disp_row[yp] = u16x4{f2h(hx), f2h(hy), f2h(hz), f2h(0.0f * sgn)};
-            if (f32_row) {
-                float *q = f32_row + (size_t)yp * 8;
-                q[0] = hx;
-                q[1] = hy;
-                q[2] = hz;
-            }
-        }
+    // optional FP32 debug image: 8 pre-quantisation channels per texel [hx,hy,hz,gx,gy,dhx_dx,foam,J]
+    static OW_DEV void f32_put(GBuf f32_c, uint32_t tex, int o, int ch, float v) {
+#if OW_DEVICE_BUILD
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), f32_c.r, (int)(tex * 32u + (uint32_t)ch * 4u), (int)((uint32_t)(T * o) * 32u), 0);
+#else
+        __builtin_memcpy(f32_c.p + tex * 32u + (uint32_t)ch * 4u + (uint32_t)(T * o) * 32u, &v, 4);
+#endif
     }
 
-    // pair 1 (layers 2,3): Jacobian, foam RMW, normalised slopes (fft_unpack.glsl:52-67)
-    // f32_row (optional): 8 pre-quantisation channels per texel [hx,hy,hz,gx,gy,dhx_dx,foam,J]
-    static OW_DEV void unpack_normal(const cplx *l2, const cplx *l3, const float *dhy_dx, int t, int xp,
-                                     const CascadeFrame &cf, u16x4 *__restrict__ norm_row, float *__restrict__ f32_row) {
+    // layer 2 done (fft_unpack.glsl:54): dhy_dz = re, dhx_dx = im of output ordinal o: OutMap<N>::slot_of(o) of d
+    // (nothing to compute: the caller keeps the layer's registers)
+    // layer 3 done (fft_unpack.glsl:55-66): Jacobian, foam RMW, gy; gy_foam[o] = packed halves (gy | foam << 16)
+    template <bool F32>
+    static OW_DEV void after_layer3(const cplx *l3, const cplx *l2, const uint16_t *foam_prev, uint32_t *gy_foam,
+                                    uint32_t tex, const CascadeFrame &cf, GBuf f32_c) {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
-            const int yp = t + T * o;
             const int sl = OutMap<N>::slot_of(o);
-            const float sgn = ((xp ^ yp) & 1) ? -1.0f : 1.0f;
-            const float dhy_dz = l2[sl].x * sgn, dhx_dx = l2[sl].y * sgn;
-            const float dhz_dz = l3[sl].x * sgn, dhz_dx = l3[sl].y * sgn;
-
+            const float dhy_dz = l2[sl].x, dhx_dx = l2[sl].y;
+            const float dhz_dz = l3[sl].x, dhz_dx = l3[sl].y;
             const float jac = (1.0f + dhx_dx) * (1.0f + dhz_dz) - dhz_dx * dhz_dx;
             const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
-            float foam = h2f(norm_row[yp].w);
+            float foam = h2f(foam_prev[o]);
             foam = mul_rn(foam, cf.foam_decay);
             foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
             foam = fminf(fmaxf(foam, 0.0f), 1.0f);
-            const float gx = dhy_dx[o] / (1.0f + fabsf(dhx_dx));
             const float gy = dhy_dz / (1.0f + fabsf(dhz_dz));
-
-            norm_row[yp] = u16x4{f2h(gx), f2h(gy), f2h(dhx_dx), f2h(foam)};
-            if (f32_row) {
-                float *q = f32_row + (size_t)yp * 8;
-                q[3] = gx;
-                q[4] = gy;
-                q[5] = dhx_dx;
-                q[6] = foam;
-                q[7] = jac;
+            gy_foam[o] = (uint32_t)f2h(gy) | ((uint32_t)f2h(foam) << 16);
+            if (F32) {
+                f32_put(f32_c, tex, o, 4, gy);
+                f32_put(f32_c, tex, o, 6, foam);
+                f32_put(f32_c, tex, o, 7, jac);
             }
         }
     }
-};
-
-// Row IFFT of one layer held in d[] (lane view of the exchange points is in the callers: they must
-// separate *_write and *_read with a wave-level sync).
-template <int N>
-struct RowFft {
-    static constexpr int S = plan_S(N);
+    // layer 1 done (fft_unpack.glsl:45,53,65-67): gx = dhy_dx / (1 + |dhx_dx|), normal map store; hz = l1.re stays in l1
+    template <bool F32, int AUX>
+    static OW_DEV void after_layer1(const cplx *l1, const float *dhx_dx, const uint32_t *gy_foam, uint32_t tex, GBuf norm_c,
+                                    GBuf f32_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            const float gx = l1[sl].y / (1.0f + fabsf(dhx_dx[o]));
+            gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u,
+                          u16x4{f2h(gx), (uint16_t)(gy_foam[o] & 0xFFFFu), f2h(dhx_dx[o]), (uint16_t)(gy_foam[o] >> 16)});
+            if (F32) {
+                f32_put(f32_c, tex, o, 3, gx);
+                f32_put(f32_c, tex, o, 5, dhx_dx[o]);
+            }
+        }
+    }
+    // layer 0 done (fft_unpack.glsl:44-50): displacement = (hx, hy, hz, 0) * sign; the sign only survives in the
+    // zero of .w (0 * -1 = -0): sign bit = parity of x' + y', and y' = t + T*o has the parity of t
+    template <bool F32, int AUX>
+    static OW_DEV void after_layer0(const cplx *l0, const float *hz, int t, int xp, uint32_t tex, GBuf disp_c, GBuf f32_c) {
+        const uint16_t w = (uint16_t)(((xp ^ t) & 1) << 15);
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            gstore8h<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(l0[sl].x), f2h(l0[sl].y), f2h(hz[o]), w});
+            if (F32) {
+                f32_put(f32_c, tex, o, 0, l0[sl].x);
+                f32_put(f32_c, tex, o, 1, l0[sl].y);
+                f32_put(f32_c, tex, o, 2, hz[o]);
+            }
+        }
+    }
 };
 
 // ------------------------------------------------------------------------------------

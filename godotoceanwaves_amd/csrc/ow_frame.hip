@@ -7,15 +7,15 @@ bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n ==
 
 template <int N>
 static hipError_t launch1(int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
-    const int blocks = slots * (N / plan_p1_rows(N));
-    hipLaunchKernelGGL((k_pass1<N>), dim3(blocks), dim3(64 * plan_p1_waves(N)), 0, s, buf, args, DebugArgs{});
+    const int blocks = slots * (N / kWgRows);
+    hipLaunchKernelGGL((k_pass1<N>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 template <int N>
 static hipError_t launch2(int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
-    const int blocks = slots * (N / plan_rows_per_wave(N));
-    if (buf.f32) hipLaunchKernelGGL((k_pass2<N, true>), dim3(blocks), dim3(64), 0, s, buf, args, DebugArgs{});
-    else hipLaunchKernelGGL((k_pass2<N, false>), dim3(blocks), dim3(64), 0, s, buf, args, DebugArgs{});
+    const int blocks = slots * (N / kWgRows);
+    if (buf.f32) hipLaunchKernelGGL((k_pass2<N, true>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
+    else hipLaunchKernelGGL((k_pass2<N, false>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 

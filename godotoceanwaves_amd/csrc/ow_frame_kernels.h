@@ -6,13 +6,20 @@
 //   k_pass2 : row IFFT (fft_compute.glsl 2nd dispatch) --> fft_unpack.glsl fused (sign, Jacobian,
 //             foam RMW, RGBA16F stores)
 //
-// A wavefront (64 lanes) owns plan_rows_per_wave(N) map rows x 4 layers.  The two LDS exchanges of a
-// row transform stay inside the wave, whose DS instructions execute in order; wave_sync() only pins
-// the compiler's ordering (no s_barrier).  Pass 1 groups the waves of 4 consecutive rows into one
-// workgroup and releases their stores together so whole 128-byte lines of T reach L2 at once.
+// N/16 lanes own one map row (16 points per lane) and transform its 4 packed layers one after the other,
+// so a lane never holds more than one layer in flight (<= 128 VGPRs: 4 waves per SIMD, 16 rows of a
+// 1024-map resident per CU).  The two LDS exchanges of a row transform stay inside the wave for N <= 1024
+// (DS instructions of one wave execute in order; wave_sync() only pins the compiler's ordering).
+// A workgroup is the lanes of 8 consecutive rows: they share one LDS copy of the twiddle table and, in
+// pass 1, transpose each finished layer through LDS so that T is written in full 64-byte requests.
+// Workgroup barriers are LDS-only (lds_barrier): they never wait for global loads or stores, so the stores
+// of one layer drain underneath the next layer's butterflies.
 #pragma once
 #include "ow_kernels.h"
 
+#ifndef OW_P1_WAVES
+#define OW_P1_WAVES 4
+#endif
 namespace ow {
 
 // VAR bits (kbench only; the product instantiates VAR = 0):
@@ -32,6 +39,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier, no vmcnt drain
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// sync between the lanes that share a row's LDS region
+template <int N>
+__device__ __forceinline__ void row_sync() {
+    if constexpr (plan_row_spans_waves(N)) lds_barrier();
+    else wave_sync();
+}
 
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned v;
@@ -44,181 +63,234 @@ __device__ __forceinline__ unsigned xcc_id() {
         ts[k] = wall_clock64();                    \
     }
 
-// row IFFT of the P points in d[] (lane t of the row), exchanging through this row's LDS buffer
+// copy the constant twiddle table (global, plan_tw_total(N) entries) into this workgroup's LDS
+template <int N>
+__device__ __forceinline__ void load_twiddles(cplx *tw_lds, const cplx *__restrict__ tw) {
+    for (int i = threadIdx.x; i < plan_tw_total(N); i += plan_wg_threads(N)) tw_lds[i] = tw[i];
+    lds_barrier();
+}
+
+// row IFFT of the 16 points in d[] (lane t of the row), exchanging through this row's LDS buffer
 template <int N>
 __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw) {
     fft_stage_compute<N, 0>(d, t, tw);
     fft_stage_write<N, 0>(d, t, lds_row);
-    wave_sync();
+    row_sync<N>();
     fft_stage_read<N, 1>(d, t, lds_row);
-    wave_sync();
+    row_sync<N>();
     fft_stage_compute<N, 1>(d, t, tw);
     if constexpr (plan_S(N) == 3) {
         fft_stage_write<N, 1>(d, t, lds_row);
-        wave_sync();
+        row_sync<N>();
         fft_stage_read<N, 2>(d, t, lds_row);
-        wave_sync();
+        row_sync<N>();
         fft_stage_compute<N, 2>(d, t, tw);
     }
 }
 
-// blockIdx -> (launch slot, first row of the block); ROWS rows per block
-template <int N, int ROWS>
-__device__ __forceinline__ void block_to_rows(int &slot, int &row0) {
-    constexpr int BPC = N / ROWS;
-    const int b = blockIdx.x;
-    slot = b / BPC;
-    row0 = (b % BPC) * ROWS;
+// Pass-1 block -> (launch slot, first row).  The two blocks that write the two 64-byte halves of the same
+// 128-byte lines of T (rows 16g..16g+7 and 16g+8..16g+15) get block indices b and b+8: the dispatcher places
+// block b on XCD b % 8, so both halves meet in the same L2 before they are written back (speed only).
+template <int N>
+__device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
+    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    const int grow = (x + 8 * (i >> 1)) * 16 + (i & 1) * 8;  // row index over all launch slots
+    slot = grow / N;
+    row0 = grow % N;
+}
+template <int N>
+__device__ __forceinline__ void p2_block_to_rows(int &slot, int &row0) {
+    constexpr int BPC = N / kWgRows;
+    slot = blockIdx.x / BPC;
+    row0 = (blockIdx.x % BPC) * kWgRows;
 }
 
-template <int N, int VAR = 0>
-__global__ __launch_bounds__(64 * plan_p1_waves(N)) void k_pass1(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
-    constexpr int Tn = plan_T(N), P = plan_P(N), W = plan_p1_waves(N);
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_lds_cplx(N) * W];
-    int slot, row0;
-    block_to_rows<N, plan_p1_rows(N)>(slot, row0);
-    const CascadeFrame cf = args.c[slot];
-    const int tau = threadIdx.x;
-    const int rw = tau / Tn, t = tau % Tn;  // row inside the block, lane inside the row
-    const int y = row0 + rw;
-    const size_t plane = (size_t)N * N;
-    cplx *lds_row = lds + rw * plan_region_cplx(N);  // FFT exchanges never leave the wave that owns the row
-    f32x4 *Tc = buf.T + cf.cascade * plane * 2;
+template <int W>
+__device__ __forceinline__ void write_stamps(const unsigned long long *ts, const DebugArgs &dbg) {
+    if ((threadIdx.x & 63) == 0) {
+        Stamp st;
+        for (int k = 0; k < 6; ++k) st.t[k] = ts[k];
+        st.xcc = xcc_id();
+        st.pad = 0;
+        dbg.stamps[blockIdx.x * W + threadIdx.x / 64] = st;
+    }
+}
 
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+// ---------------------------------------------------------------------------------------------------
+// PASS 1.  One block = 8 rows.  Load + modulate, then per layer {spectrum from h, row IFFT, staged
+// transposed store}.
+// ---------------------------------------------------------------------------------------------------
+template <int N, int VAR = 0, int AUX_T = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
+    constexpr int Tn = plan_T(N), P = kP;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    cplx *tw_lds = lds;  // table first: its DS offsets then fit the 16-bit immediate field
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    // row inside the block (wave-uniform when a wave carries a single row) and lane inside the row
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    constexpr bool kFft = (VAR & 4) == 0;
+    constexpr bool kStore = (VAR & 2) == 0;
+    constexpr bool kLoad = (VAR & 1) == 0;
+    unsigned long long ts[(VAR & 8) ? 6 : 1] = {0};
     OW_STAMP(0, t)
+
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    const int y = row0 + rw;
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 16u);
+    const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+
     cplx h[P];
-    if constexpr ((VAR & 1) != 0) {
+    if constexpr (kLoad) {
+        Pass1<N>::load_modulate(h, (uint32_t)(y * N + t), h0_c, om_c, cf.time);
+    } else {
 #pragma unroll
         for (int j = 0; j < P; ++j) h[j] = cplx{(float)(t + j) * 1e-3f + cf.time, (float)(t - j) * 1e-3f};
-    } else {
-        Pass1<N>::load_modulate(h, t, buf.h0 + cf.cascade * plane + (size_t)y * N,
-                                buf.omega + cf.cascade * plane + (size_t)y * N, cf.time);
     }
+    load_twiddles<N>(tw_lds, buf.tw);
     OW_STAMP(1, h[0].x)
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
-    constexpr bool kFft = (VAR & 4) == 0;
-    constexpr bool kStore = (VAR & 2) == 0;
     float keep = 0.0f;
 
 #pragma unroll
-    for (int pair = 0; pair < 2; ++pair) {
-        cplx a[P], b[P];
-        if (pair == 0) {
-            Pass1<N>::template layer_input<0>(a, h, t, ky, dkx);
-            Pass1<N>::template layer_input<1>(b, h, t, ky, dkx);
-        } else {
-            Pass1<N>::template layer_input<2>(a, h, t, ky, dkx);
-            Pass1<N>::template layer_input<3>(b, h, t, ky, dkx);
+    for (int L = 0; L < kLayers; ++L) {
+        cplx d[P];
+        OW_SCHED_FENCE();
+        {
+            // the wave-vector terms are recomputed per layer (a few VALU ops), not held across the FFTs
+            const float kyo = opaque(ky), dkxo = opaque(dkx);
+            const int to = opaque(t);
+#pragma unroll
+            for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
+            if (L == 0) Pass1<N>::template layer_input<0>(d, h, to, kyo, dkxo);
+            if (L == 1) Pass1<N>::template layer_input<1>(d, h, to, kyo, dkxo);
+            if (L == 2) Pass1<N>::template layer_input<2>(d, h, to, kyo, dkxo);
+            if (L == 3) Pass1<N>::template layer_input<3>(d, h, to, kyo, dkxo);
         }
-        if constexpr (kFft) {
-            row_ifft<N>(a, t, lds_row, buf.tw);
-            row_ifft<N>(b, t, lds_row, buf.tw);
-        }
-        if (pair == 0) { OW_STAMP(2, b[0].x) } else { OW_STAMP(3, b[0].x) }
+        OW_SCHED_FENCE();
+        if constexpr (kFft) row_ifft<N>(d, t, lds_row, tw_lds);
+        if (L == 1) { OW_STAMP(2, d[0].x) }
+        if (L == 3) { OW_STAMP(3, d[0].x) }
         if (kStore || dbg.never_true) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                wave_sync();  // this wave's own exchange reads are done (in order); pin the compiler
-                Pass1<N>::stage_write(a, b, t, r, lds_row);
-                __syncthreads();
-                Pass1<N>::stage_store(tau, r, pair, row0, lds, Tc);
-                __syncthreads();
-            }
+            row_sync<N>();  // the row's exchange reads are done before its region becomes the staging image
+            Pass1<N>::stage_write(d, t, lds_row);
+            lds_barrier();
+            Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+            lds_barrier();
         } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) keep += a[j].x + a[j].y + b[j].x + b[j].y;
+            for (int j = 0; j < P; ++j) keep += d[j].x + d[j].y;
         }
     }
-    if (!kStore && keep == 12345.678f) Tc[t] = f32x4{keep, keep, keep, keep};
+    if (!kStore && keep == 12345.678f) buf.T[t] = cplx{keep, keep};
     if constexpr ((VAR & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = wall_clock64();
-        if ((threadIdx.x & 63) == 0) {
-            Stamp st;
-            for (int k = 0; k < 6; ++k) st.t[k] = ts[k];
-            st.xcc = xcc_id();
-            st.pad = 0;
-            dbg.stamps[blockIdx.x * W + threadIdx.x / 64] = st;
-        }
+        write_stamps<(plan_wg_threads(N) + 63) / 64>(ts, dbg);
     }
 }
 
-template <int N, bool F32, int VAR = 0>
-__global__ __launch_bounds__(64) void k_pass2(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
-    constexpr int Tn = plan_T(N), P = plan_P(N);
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_lds_cplx(N)];
-    int slot, row0;
-    block_to_rows<N, plan_rows_per_wave(N)>(slot, row0);
-    const CascadeFrame cf = args.c[slot];
-    const int lane = threadIdx.x, rw = lane / Tn, t = lane % Tn;
-    const int xp = row0 + rw;
-    const size_t plane = (size_t)N * N;
-    cplx *lds_row = lds + rw * plan_region_cplx(N);
-    const f32x4 *Tc = buf.T + cf.cascade * plane * 2;
-    const size_t row_off = cf.cascade * plane + (size_t)xp * N;
-    float *f32_row = F32 ? buf.f32 + row_off * 8 : nullptr;
+// ---------------------------------------------------------------------------------------------------
+// PASS 2.  One block = 8 rows x' of T (the rows only share the twiddle table).  Layer order 2, 3, 1, 0
+// (see Pass2 in ow_device.h).
+// ---------------------------------------------------------------------------------------------------
+template <int N, bool F32, int VAR = 0, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
+    constexpr int Tn = plan_T(N), P = kP;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    cplx *tw_lds = lds;  // table first: its DS offsets then fit the 16-bit immediate field
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
-
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    constexpr bool kLoad = (VAR & 1) == 0;
+    unsigned long long ts[(VAR & 8) ? 6 : 1] = {0};
     OW_STAMP(0, t)
-    float dhy_dx[P];
+
+    int slot, row0;
+    p2_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    const int xp = row0 + rw;
+    const uint32_t tex = (uint32_t)(xp * N + t);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
+
     float keep = 0.0f;
+    auto fetch = [&](cplx *d, int layer) {
+        OW_SCHED_FENCE();  // loads are issued here, not hoisted above the previous layer's transform
+        if constexpr (kLoad) {
+            Pass2<N>::template load_layer<AUX_T>(d, t, xp, layer, T_c);
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) d[j] = cplx{(float)(t + j + layer) * 1e-3f + cf.time, (float)(t - j) * 1e-3f};
+        }
+    };
+
+    float dhx_dx[P];
+    uint32_t gy_foam[P];
     {
-        cplx a[P], b[P];
-        if constexpr ((VAR & 1) != 0) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) { a[j] = cplx{(float)(t + j) * 1e-3f + cf.time, (float)(t - j) * 1e-3f}; b[j] = cplx{a[j].y, a[j].x}; }
+        cplx l2[P];
+        fetch(l2, 2);
+        load_twiddles<N>(tw_lds, buf.tw);
+        OW_STAMP(1, l2[0].x)
+        if constexpr (kFft) row_ifft<N>(l2, t, lds_row, tw_lds);
+        cplx l3[P];
+        uint16_t foam_prev[P];
+        fetch(l3, 3);
+        if constexpr (kLoad) {
+            Pass2<N>::load_foam(foam_prev, tex, norm_c);
         } else {
-            Pass2<N>::load_pair(a, b, t, xp, 0, Tc);
+#pragma unroll
+            for (int j = 0; j < P; ++j) foam_prev[j] = 0;
         }
-        if constexpr ((VAR & 8) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        OW_STAMP(1, a[0].x)
-        if constexpr (kFft) {
-            row_ifft<N>(a, t, lds_row, buf.tw);
-            row_ifft<N>(b, t, lds_row, buf.tw);
-        }
-        OW_STAMP(2, b[0].x)
+        if constexpr (kFft) row_ifft<N>(l3, t, lds_row, tw_lds);
+        OW_STAMP(2, l3[0].x)
+        Pass2<N>::template after_layer3<F32 && kStore>(l3, l2, foam_prev, gy_foam, tex, cf, f32_c);
+#pragma unroll
+        for (int o = 0; o < P; ++o) dhx_dx[o] = l2[OutMap<N>::slot_of(o)].y;
+    }
+    float hz[P];
+    {
+        cplx l1[P];
+        fetch(l1, 1);
+        if constexpr (kFft) row_ifft<N>(l1, t, lds_row, tw_lds);
         if (kStore || dbg.never_true) {
-            Pass2<N>::unpack_displacement(a, b, dhy_dx, t, xp, buf.disp + row_off, f32_row);
+            Pass2<N>::template after_layer1<F32, AUX_O>(l1, dhx_dx, gy_foam, tex, norm_c, f32_c);
         } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) { keep += a[j].x + a[j].y + b[j].x; dhy_dx[j] = b[j].y; }
+            for (int j = 0; j < P; ++j) keep += l1[j].y + dhx_dx[j] + (float)gy_foam[j];
         }
+#pragma unroll
+        for (int o = 0; o < P; ++o) hz[o] = l1[OutMap<N>::slot_of(o)].x;
     }
     {
-        cplx a[P], b[P];
-        if constexpr ((VAR & 1) != 0) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) { a[j] = cplx{(float)(t + j) * 2e-3f + cf.time, (float)(t - j) * 3e-3f}; b[j] = cplx{a[j].y, a[j].x}; }
-        } else {
-            Pass2<N>::load_pair(a, b, t, xp, 1, Tc);
-        }
-        if constexpr (kFft) {
-            row_ifft<N>(a, t, lds_row, buf.tw);
-            row_ifft<N>(b, t, lds_row, buf.tw);
-        }
-        OW_STAMP(3, b[0].x)
+        cplx l0[P];
+        fetch(l0, 0);
+        if constexpr (kFft) row_ifft<N>(l0, t, lds_row, tw_lds);
+        OW_STAMP(3, l0[0].x)
         if (kStore || dbg.never_true) {
-            Pass2<N>::unpack_normal(a, b, dhy_dx, t, xp, cf, buf.norm + row_off, f32_row);
+            Pass2<N>::template after_layer0<F32, AUX_O>(l0, hz, t, xp, tex, disp_c, f32_c);
         } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) keep += a[j].x + a[j].y + b[j].x + b[j].y + dhy_dx[j];
+            for (int j = 0; j < P; ++j) keep += l0[j].x + l0[j].y + hz[j];
         }
     }
     if (!kStore && keep == 12345.678f) buf.disp[t] = u16x4{1, 2, 3, 4};
     if constexpr ((VAR & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = wall_clock64();
-        if (lane == 0) {
-            Stamp st;
-            for (int k = 0; k < 6; ++k) st.t[k] = ts[k];
-            st.xcc = xcc_id();
-            st.pad = 0;
-            dbg.stamps[blockIdx.x] = st;
-        }
+        write_stamps<(plan_wg_threads(N) + 63) / 64>(ts, dbg);
     }
 }
 

@@ -9,7 +9,7 @@ namespace ow {
 struct DeviceBuffers {
     f32x4 *h0;      // [layers][N][N] float4   (the `spectrum` texture, wave_generator.gd:31)
     float *omega;   // [layers][N][N]          FP32 dispersion plane
-    f32x4 *T;      // [layers][2 pairs][N/4 y/4][N x'][4 y%4] float4 = two packed layers: transposed intermediate
+    cplx *T;        // [layers][4 packed layers][N/16 y/16][N x'][16 y%16] complex: transposed intermediate
     u16x4 *disp;    // [layers][N][N] RGBA16F
     u16x4 *norm;    // [layers][N][N] RGBA16F (foam in .a)
     float *f32;     // [layers][N][N][8] or nullptr

@@ -230,7 +230,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         return bail(fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #ptr, (size_t)(bytes)));
     OW_ALLOC(c->buf.h0, L * pl * sizeof(ow::f32x4));                  // spectrum (R32G32B32A32_SFLOAT, :31)
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
-    OW_ALLOC(c->buf.T, L * pl * 2 * sizeof(ow::f32x4));      // half of the reference's fft_buffer (:33)
+    OW_ALLOC(c->buf.T, L * pl * ow::kLayers * sizeof(ow::cplx));  // half of the reference's fft_buffer (:33)
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -396,21 +396,21 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     if (!out) return fail(OW_ERR_INVALID, "null output");
     OW_HIP(hipSetDevice(c->device));
     const size_t pl = plane(c), n = (size_t)c->n;
-    std::vector<ow::f32x4> t(pl * 2);
-    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + cascade * pl * 2, t.size() * sizeof(ow::f32x4), hipMemcpyDeviceToHost, c->stream));
+    std::vector<ow::cplx> t(pl * ow::kLayers);
+    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + cascade * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
-    // device layout T[pair][y/4][x'][y%4] float4  ->  reference half-0-after-transpose layout [layer][row = x'][col = y]
-    for (size_t xp = 0; xp < n; ++xp)
-        for (size_t y = 0; y < n; ++y)
-            for (int pr = 0; pr < 2; ++pr) {
-                const ow::f32x4 v = t[ow::t_unit((int)n, pr, (int)xp, (int)y)];
-                float *o0 = out + (((size_t)(2 * pr) * n + xp) * n + y) * 2;
-                float *o1 = out + (((size_t)(2 * pr + 1) * n + xp) * n + y) * 2;
-                o0[0] = v.x;
-                o0[1] = v.y;
-                o1[0] = v.z;
-                o1[1] = v.w;
+    // device layout T[layer][y/16][x'][y%16]  ->  reference half-0-after-transpose layout [layer][row = x'][col = y].
+    // The device rows carry the x' half of the ifftshift sign, (-1)^x' (see Pass1::rot): taken out again here.
+    for (int layer = 0; layer < ow::kLayers; ++layer)
+        for (size_t xp = 0; xp < n; ++xp) {
+            const float sgn = (xp & 1) ? -1.0f : 1.0f;
+            for (size_t y = 0; y < n; ++y) {
+                const ow::cplx v = t[ow::t_unit((int)n, layer, (int)xp, (int)y)];
+                float *o = out + (((size_t)layer * n + xp) * n + y) * 2;
+                o[0] = v.x * sgn;
+                o[1] = v.y * sgn;
             }
+        }
     return OW_OK;
 }
 

@@ -16,14 +16,14 @@ namespace {
 // a block of NT threads; row of thread tau = tau / T; each row has its own LDS region (plan_region_cplx)
 template <int N, int NT>
 struct Block {
-    static constexpr int Tn = plan_T(N), P = plan_P(N);
+    static constexpr int Tn = plan_T(N), P = kP;
     std::vector<cplx> lds = std::vector<cplx>(plan_region_cplx(N) * (NT / Tn));
     std::vector<cplx> tw;
     Block() { fill_twiddles<N>(tw); }
     cplx *row(int tau) { return lds.data() + (tau / Tn) * plan_region_cplx(N); }
 
     // row IFFT of d[tau][P] for all threads in lockstep (mirrors row_ifft<N> in ow_frame_kernels.h;
-    // every loop below is one phase between two wave_sync()s)
+    // every loop below is one phase between two row_sync()s)
     void row_ifft(cplx (*d)[P]) {
         for (int l = 0; l < NT; ++l) fft_stage_compute<N, 0>(d[l], l % Tn, tw.data());
         for (int l = 0; l < NT; ++l) fft_stage_write<N, 0>(d[l], l % Tn, row(l));
@@ -39,11 +39,11 @@ struct Block {
 
 template <int N>
 void rows_fft(const float *in, float *out, int rows) {
-    constexpr int Tn = plan_T(N), P = plan_P(N), RW = plan_rows_per_wave(N);
-    Block<N, 64> w;
-    static cplx d[64][P];
-    for (int r0 = 0; r0 < rows; r0 += RW) {
-        for (int l = 0; l < 64; ++l) {
+    constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
+    Block<N, NT> w;
+    static cplx d[NT][P];
+    for (int r0 = 0; r0 < rows; r0 += kWgRows) {
+        for (int l = 0; l < NT; ++l) {
             const int rw = l / Tn, t = l % Tn;
             for (int j = 0; j < P; ++j) {
                 const int x = fft_in_index<N>(t, j);
@@ -51,7 +51,7 @@ void rows_fft(const float *in, float *out, int rows) {
             }
         }
         w.row_ifft(d);
-        for (int l = 0; l < 64; ++l) {
+        for (int l = 0; l < NT; ++l) {
             const int rw = l / Tn, t = l % Tn;
             for (int o = 0; o < P; ++o) {
                 const cplx v = d[l][OutMap<N>::slot_of(o)];
@@ -64,63 +64,70 @@ void rows_fft(const float *in, float *out, int rows) {
 
 template <int N>
 void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, float *f32) {
-    constexpr int Tn = plan_T(N), P = plan_P(N), RW = plan_rows_per_wave(N);
-    constexpr int NT1 = 64 * plan_p1_waves(N), ROWS1 = plan_p1_rows(N);
+    constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
-    f32x4 *Tc = reinterpret_cast<f32x4 *>(Tbuf);
+    const uint32_t plane = (uint32_t)N * N;
+    const GBuf h0_c = make_gbuf(h0, plane * 16u), om_c = make_gbuf(omega, plane * 4u), T_c = make_gbuf(Tbuf, t_cascade_bytes(N));
+    const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), f32_c = make_gbuf(f32, plane * 32u);
+    Block<N, NT> w;
     // ---- pass 1 (mirrors k_pass1) ----
     {
-        Block<N, NT1> w;
-        static cplx h[NT1][P], a[NT1][P], b[NT1][P];
-        for (int row0 = 0; row0 < N; row0 += ROWS1) {
-            for (int l = 0; l < NT1; ++l) {
-                const int y = row0 + l / Tn;
-                Pass1<N>::load_modulate(h[l], l % Tn, reinterpret_cast<const f32x4 *>(h0) + (size_t)y * N, omega + (size_t)y * N, cf.time);
+        static cplx h[NT][P], d[NT][P];
+        for (int row0 = 0; row0 < N; row0 += kWgRows) {
+            for (int l = 0; l < NT; ++l) {
+                const int y = row0 + l / Tn, t = l % Tn;
+                Pass1<N>::load_modulate(h[l], (uint32_t)(y * N + t), h0_c, om_c, cf.time);
             }
-            for (int pair = 0; pair < 2; ++pair) {
-                for (int l = 0; l < NT1; ++l) {
+            for (int L = 0; L < kLayers; ++L) {
+                for (int l = 0; l < NT; ++l) {
                     const int y = row0 + l / Tn, t = l % Tn;
                     const float ky = (float)(y - N / 2) * dky;
-                    if (pair == 0) {
-                        Pass1<N>::template layer_input<0>(a[l], h[l], t, ky, dkx);
-                        Pass1<N>::template layer_input<1>(b[l], h[l], t, ky, dkx);
-                    } else {
-                        Pass1<N>::template layer_input<2>(a[l], h[l], t, ky, dkx);
-                        Pass1<N>::template layer_input<3>(b[l], h[l], t, ky, dkx);
-                    }
+                    if (L == 0) Pass1<N>::template layer_input<0>(d[l], h[l], t, ky, dkx);
+                    if (L == 1) Pass1<N>::template layer_input<1>(d[l], h[l], t, ky, dkx);
+                    if (L == 2) Pass1<N>::template layer_input<2>(d[l], h[l], t, ky, dkx);
+                    if (L == 3) Pass1<N>::template layer_input<3>(d[l], h[l], t, ky, dkx);
                 }
-                w.row_ifft(a);
-                w.row_ifft(b);
-                for (int r = 0; r < 2; ++r) {
-                    for (int l = 0; l < NT1; ++l) Pass1<N>::stage_write(a[l], b[l], l % Tn, r, w.row(l));
-                    // __syncthreads()
-                    for (int l = 0; l < NT1; ++l) Pass1<N>::stage_store(l, r, pair, row0, w.lds.data(), Tc);
-                    // __syncthreads()
-                }
+                w.row_ifft(d);
+                for (int l = 0; l < NT; ++l) Pass1<N>::stage_write(d[l], l % Tn, w.row(l));
+                // lds_barrier()
+                for (int l = 0; l < NT; ++l) Pass1<N>::template stage_store<0>(l, L, row0, w.lds.data(), T_c);
+                // lds_barrier()
             }
         }
     }
-    // ---- pass 2 (mirrors k_pass2) ----
+    // ---- pass 2 (mirrors k_pass2: layers 2, 3, 1, 0) ----
     {
-        Block<N, 64> w;
-        static cplx a[64][P], b[64][P];
-        static float dhy_dx[64][P];
-        for (int row0 = 0; row0 < N; row0 += RW) {
-            for (int l = 0; l < 64; ++l) Pass2<N>::load_pair(a[l], b[l], l % Tn, row0 + l / Tn, 0, Tc);
-            w.row_ifft(a);
-            w.row_ifft(b);
-            for (int l = 0; l < 64; ++l) {
-                const int xp = row0 + l / Tn;
-                Pass2<N>::unpack_displacement(a[l], b[l], dhy_dx[l], l % Tn, xp, reinterpret_cast<u16x4 *>(disp) + (size_t)xp * N,
-                                              f32 ? f32 + (size_t)xp * N * 8 : nullptr);
+        static cplx l2[NT][P], l3[NT][P], l1[NT][P], l0[NT][P];
+        static float dhx_dx[NT][P], hz[NT][P];
+        static uint32_t gy_foam[NT][P];
+        static uint16_t foam_prev[NT][P];
+        for (int row0 = 0; row0 < N; row0 += kWgRows) {
+            auto xp_of = [&](int l) { return row0 + l / Tn; };
+            auto tex_of = [&](int l) { return (uint32_t)(xp_of(l) * N + l % Tn); };
+            for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(l2[l], l % Tn, xp_of(l), 2, T_c);
+            w.row_ifft(l2);
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::template load_layer<0>(l3[l], l % Tn, xp_of(l), 3, T_c);
+                Pass2<N>::load_foam(foam_prev[l], tex_of(l), norm_c);
             }
-            for (int l = 0; l < 64; ++l) Pass2<N>::load_pair(a[l], b[l], l % Tn, row0 + l / Tn, 1, Tc);
-            w.row_ifft(a);
-            w.row_ifft(b);
-            for (int l = 0; l < 64; ++l) {
-                const int xp = row0 + l / Tn;
-                Pass2<N>::unpack_normal(a[l], b[l], dhy_dx[l], l % Tn, xp, cf, reinterpret_cast<u16x4 *>(norm) + (size_t)xp * N,
-                                        f32 ? f32 + (size_t)xp * N * 8 : nullptr);
+            w.row_ifft(l3);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_layer3<true>(l3[l], l2[l], foam_prev[l], gy_foam[l], tex_of(l), cf, f32_c);
+                else Pass2<N>::template after_layer3<false>(l3[l], l2[l], foam_prev[l], gy_foam[l], tex_of(l), cf, f32_c);
+                for (int o = 0; o < P; ++o) dhx_dx[l][o] = l2[l][OutMap<N>::slot_of(o)].y;
+            }
+            for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(l1[l], l % Tn, xp_of(l), 1, T_c);
+            w.row_ifft(l1);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_layer1<true, 0>(l1[l], dhx_dx[l], gy_foam[l], tex_of(l), norm_c, f32_c);
+                else Pass2<N>::template after_layer1<false, 0>(l1[l], dhx_dx[l], gy_foam[l], tex_of(l), norm_c, f32_c);
+                for (int o = 0; o < P; ++o) hz[l][o] = l1[l][OutMap<N>::slot_of(o)].x;
+            }
+            for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(l0[l], l % Tn, xp_of(l), 0, T_c);
+            w.row_ifft(l0);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_layer0<true, 0>(l0[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
+                else Pass2<N>::template after_layer0<false, 0>(l0[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
             }
         }
     }
