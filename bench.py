@@ -34,11 +34,14 @@ BYTES_MAP = BYTES_PASS1 + BYTES_PASS2  # 104
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--map-size", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4, help="cascades per GPU")
     ap.add_argument("--gather-every", type=int, default=0, help="RCCL all_gather of the maps every k ticks inside the timed region (0 = once, after it)")
+    ap.add_argument("--prime-ms", type=float, default=300.0,
+                    help="untimed clock priming before the W warm-up steps: the chip's DVFS needs tens of ms of load to reach its "
+                         "steady clock, and a short run would otherwise time the ramp (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline sample size in ticks (0 = auto, ~10-20 s)")
     return ap.parse_args()
@@ -120,6 +123,13 @@ def main():
     gen.update_all(UPDATE_DELTA, params)
     gen.sync()
     spectrum_ms = (time.perf_counter() - t_spec0) * 1e3
+    prime_ticks = 0
+    if args.prime_ms > 0:  # untimed: bring the clocks to their steady state (not part of W or K)
+        tp = time.perf_counter()
+        while (time.perf_counter() - tp) * 1e3 < args.prime_ms:
+            gen.run(UPDATE_DELTA, params, 50)
+            gen.sync()
+            prime_ticks += 50
     if args.warmup > 1:
         gen.run(UPDATE_DELTA, params, args.warmup - 1)
     if world > 1:
@@ -205,6 +215,7 @@ def main():
                          "tick_achieved_gbps_per_gpu": round(frame_gbps, 1), "tick_frac": round(frame_gbps / HBM_PEAK_GBPS, 4)},
             "frames_per_s": round(args.steps * world / elapsed, 2),
             "spectrum_init_ms": round(spectrum_ms, 3),
+            "clock_priming": {"ms": args.prime_ms, "ticks": prime_ticks},
         }
         if gather_ms is not None:
             out["final_gather_ms"] = round(gather_ms, 3)

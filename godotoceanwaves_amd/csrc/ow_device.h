@@ -88,17 +88,27 @@ constexpr int dft_pos(int R, int k) { return R == 16 ? 4 * (k % 4) + k / 4 : (R 
 // complex helpers
 // ------------------------------------------------------------------------------------
 #if OW_DEVICE_BUILD
+// Every helper below is ONE or TWO packed instructions: the half swap of "times i" rides on op_sel and the
+// lane-wise sign on a (+-1, -+1) constant pair, instead of v_xor + v_mov in front of a packed add.
 OW_DEV cplx cadd(cplx a, cplx b) { return a + b; }
 OW_DEV cplx csub(cplx a, cplx b) { return a - b; }
-OW_DEV cplx cmuli(cplx a) { return cplx{-a.y, a.x}; }  // i * a
-OW_DEV cplx cmul(cplx a, cplx b) { return a.xx * b + a.yy * cplx{-b.y, b.x}; }
+OW_DEV cplx cmuli(cplx a) { return a.yx * cplx{-1.0f, 1.0f}; }                                    // i * a
+OW_DEV cplx caddi(cplx a, cplx b) { return __builtin_elementwise_fma(b.yx, cplx{-1.0f, 1.0f}, a); }  // a + i * b
+OW_DEV cplx csubi(cplx a, cplx b) { return __builtin_elementwise_fma(b.yx, cplx{1.0f, -1.0f}, a); }  // a - i * b
 OW_DEV cplx cscale(cplx a, float s) { return a * s; }
+// a * (c + i s) with compile-time c, s
+OW_DEV cplx cmul_const(cplx a, float c, float sn) { return __builtin_elementwise_fma(a.yx, cplx{-sn, sn}, a * cplx{c, c}); }
+// a * b, general
+OW_DEV cplx cmul(cplx a, cplx b) { return __builtin_elementwise_fma(a.yy * cplx{-1.0f, 1.0f}, b.yx, a.xx * b); }
 #else
 OW_DEV cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
 OW_DEV cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
 OW_DEV cplx cmuli(cplx a) { return cplx{-a.y, a.x}; }  // i * a
-OW_DEV cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+OW_DEV cplx caddi(cplx a, cplx b) { return cplx{a.x - b.y, a.y + b.x}; }
+OW_DEV cplx csubi(cplx a, cplx b) { return cplx{a.x + b.y, a.y - b.x}; }
 OW_DEV cplx cscale(cplx a, float s) { return cplx{a.x * s, a.y * s}; }
+OW_DEV cplx cmul_const(cplx a, float c, float sn) { return cplx{a.x * c - a.y * sn, a.y * c + a.x * sn}; }
+OW_DEV cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 #endif
 
 // Inverse-sign (e^{+2*pi*i/R}) radix butterflies, in place.
@@ -108,15 +118,15 @@ OW_DEV void dft2(cplx &a, cplx &b) {
     b = t;
 }
 OW_DEV void dft4(cplx &a, cplx &b, cplx &c, cplx &d) {
-    cplx t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = cmuli(csub(b, d));
+    const cplx t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
     a = cadd(t0, t2);
-    b = cadd(t1, t3);
+    b = caddi(t1, t3);
     c = csub(t0, t2);
-    d = csub(t1, t3);
+    d = csubi(t1, t3);
 }
-// a * (1 + i) / sqrt(2), a * (-1 + i) / sqrt(2)
-OW_DEV cplx cmul_w8_1(cplx a) { return cscale(cadd(a, cmuli(a)), 0.70710678118654752f); }
-OW_DEV cplx cmul_w8_3(cplx a) { return cscale(csub(cmuli(a), a), 0.70710678118654752f); }
+constexpr float kH = 0.70710678118654752f;
+OW_DEV cplx cmul_w8_1(cplx a) { return cmul_const(a, kH, kH); }   // a * (1 + i) / sqrt(2)
+OW_DEV cplx cmul_w8_3(cplx a) { return cmul_const(a, -kH, kH); }  // a * (-1 + i) / sqrt(2)
 
 template <int R>
 struct Dft;
@@ -156,15 +166,15 @@ struct Dft<16> {
         dft4(v[3], v[7], v[11], v[15]);
         OW_SCHED_FENCE();
         // slot 4*k1 + n2 holds u[n2][k1]; multiply by W16^{n2*k1}
-        v[5] = cmul(v[5], cplx{c1, s1});           // W16^1
+        v[5] = cmul_const(v[5], c1, s1);           // W16^1
         v[6] = cmul_w8_1(v[6]);                    // W16^2
-        v[7] = cmul(v[7], cplx{s1, c1});           // W16^3
+        v[7] = cmul_const(v[7], s1, c1);           // W16^3
         v[9] = cmul_w8_1(v[9]);                    // W16^2
         v[10] = cmuli(v[10]);                      // W16^4
         v[11] = cmul_w8_3(v[11]);                  // W16^6
-        v[13] = cmul(v[13], cplx{s1, c1});         // W16^3
+        v[13] = cmul_const(v[13], s1, c1);         // W16^3
         v[14] = cmul_w8_3(v[14]);                  // W16^6
-        v[15] = cmul(v[15], cplx{-c1, -s1});       // W16^9
+        v[15] = cmul_const(v[15], -c1, -s1);       // W16^9
         OW_SCHED_FENCE();
         dft4(v[0], v[1], v[2], v[3]);
         dft4(v[4], v[5], v[6], v[7]);
@@ -493,13 +503,14 @@ struct Pass1 {
 
     // h[j] = h(k, t) = h0 * m + conj(h0(-k)) * conj(m),  m = exp(i * omega * time)   (spectrum_modulate.glsl:64-68)
     // for the lane's texels x = t + T*rot(j) of row y; tex = y*N + t (texel index of the lane's first point)
+    template <int AUX = 0>
     static OW_DEV void load_modulate(cplx *h, uint32_t tex, GBuf h0_c, GBuf om_c, float time) {
         f32x4 v[P];
         float om[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            v[j] = gload16(h0_c, tex * 16u, (uint32_t)(T * rot(j)) * 16u);
-            om[j] = gload4(om_c, tex * 4u, (uint32_t)(T * rot(j)) * 4u);
+            v[j] = gload16<AUX>(h0_c, tex * 16u, (uint32_t)(T * rot(j)) * 16u);
+            om[j] = gload4<AUX>(om_c, tex * 4u, (uint32_t)(T * rot(j)) * 4u);
         }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
@@ -623,7 +634,7 @@ struct Pass2 {
             foam = mul_rn(foam, cf.foam_decay);
             foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
             foam = fminf(fmaxf(foam, 0.0f), 1.0f);
-            const float gy = dhy_dz / (1.0f + fabsf(dhz_dz));
+            const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));  // 1-ulp reciprocal: far inside the FP16 output step
             gy_foam[o] = (uint32_t)f2h(gy) | ((uint32_t)f2h(foam) << 16);
             if (F32) {
                 f32_put(f32_c, tex, o, 4, gy);
@@ -639,7 +650,7 @@ struct Pass2 {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
             const int sl = OutMap<N>::slot_of(o);
-            const float gx = l1[sl].y / (1.0f + fabsf(dhx_dx[o]));
+            const float gx = l1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o]));
             gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u,
                           u16x4{f2h(gx), (uint16_t)(gy_foam[o] & 0xFFFFu), f2h(dhx_dx[o]), (uint16_t)(gy_foam[o] >> 16)});
             if (F32) {

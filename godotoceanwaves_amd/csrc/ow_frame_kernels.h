@@ -31,7 +31,7 @@ struct Stamp {
 struct DebugArgs {
     Stamp *stamps;
     int never_true;
-    int pad;
+    int stagger;  // experiment: low byte = s_sleep(127) count for the delayed half of the blocks, next byte = which half
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -120,7 +120,7 @@ __device__ __forceinline__ void write_stamps(const unsigned long long *ts, const
 // PASS 1.  One block = 8 rows.  Load + modulate, then per layer {spectrum from h, row IFFT, staged
 // transposed store}.
 // ---------------------------------------------------------------------------------------------------
-template <int N, int VAR = 0, int AUX_T = kAuxDefault>
+template <int N, int VAR = 0, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
     constexpr int Tn = plan_T(N), P = kP;
     __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
@@ -139,6 +139,11 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
 
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
+    if (dbg.stagger) {  // experiment: de-phase the blocks (all of them start together and would otherwise load / store in lockstep)
+        const int groups = (dbg.stagger >> 16) & 0xff, shift = (dbg.stagger >> 8) & 0xff, unit = dbg.stagger & 0xff;
+        const int g = (blockIdx.x >> shift) % groups;
+        for (int i = 0; i < g * unit; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 clocks = ~0.43 us
+    }
     const CascadeFrame cf = args.c[slot];
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 16u);
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
 
     cplx h[P];
     if constexpr (kLoad) {
-        Pass1<N>::load_modulate(h, (uint32_t)(y * N + t), h0_c, om_c, cf.time);
+        Pass1<N>::template load_modulate<AUX_H>(h, (uint32_t)(y * N + t), h0_c, om_c, cf.time);
     } else {
 #pragma unroll
         for (int j = 0; j < P; ++j) h[j] = cplx{(float)(t + j) * 1e-3f + cf.time, (float)(t - j) * 1e-3f};
