@@ -14,6 +14,9 @@
  *      files where they lie under /root/reference) and run stage by stage
  *      against this restatement; fixtures committed under tests/golden/.
  *   2. an independent NumPy FP64 twin (tests/np_twin.py) + FFT identities.
+ * STATUS: pinned -- tests/test_oracle_ref.py holds every stage (spectrum texture,
+ * butterfly table, fft_buffer, RGBA16F maps incl. the FP16 foam recurrence)
+ * BIT-exact against (1) and against the committed golden vectors.
  *
  * Arithmetic contract (this is what "the reference result" means here):
  *   - IEEE binary32 +,-,*,/,sqrt, no FMA contraction (-ffp-contract=off),

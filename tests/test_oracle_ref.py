@@ -1,0 +1,90 @@
+"""Pins the hand-written CPU oracle (oracle/ow_oracle.c) to the reference itself.
+
+1. against oracle/_ref/libglsl_ref.so -- the reference's OWN six compute shaders compiled as C++ through
+   oracle/glsl_shim.h (built only where /root/reference exists; the .so travels with the working tree):
+   every stage BIT-exact (spectrum texture, butterfly table, fft_buffer, RGBA16F maps, foam recurrence);
+2. against tests/golden/*.npz, generated from (1) by tests/golden/make_golden.py and committed: BIT-exact;
+3. against identities that share no code with either (NumPy FP64): the row pass is N*ifft, the two passes
+   are (N^2 * ifft2)^T, the f16 conversion is IEEE RTE.
+CPU only; no GPU needed."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd.presets import DEPTH, UPDATE_DELTA, cascade_preset
+from oracle import oracle as O
+from oracle import ref as R
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_*.npz")))
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libglsl_ref.so not built (needs the reference checkout)")
+@pytest.mark.parametrize("n,ci,frames", [(128, 0, 3), (128, 3, 2), (256, 2, 1)])
+def test_oracle_is_bit_exact_against_the_reference_shaders(n, ci, frames):
+    rc = R.RefCascade(n, cascade_preset(ci))
+    g = H.oracle_generator(n, [ci])
+    assert np.array_equal(rc.butterfly.view(np.uint32), O.fft_butterfly(n).view(np.uint32))  # fft_butterfly.glsl
+    for _ in range(frames):
+        rc.update(UPDATE_DELTA)
+        g.update_all(UPDATE_DELTA)
+        assert rc.time == g.params[0].time
+        assert np.array_equal(rc.spectrum.view(np.uint32), g.spectrum(0).view(np.uint32))      # spectrum_compute.glsl
+        assert np.array_equal(rc.fft[1].view(np.uint32), g.fft_half1(0).view(np.uint32))       # modulate + fft + transpose + fft
+        assert np.array_equal(rc.displacement, g.displacement(0))                                # fft_unpack.glsl
+        assert np.array_equal(rc.normal, g.normal(0))                                            # incl. the FP16 foam recurrence
+
+
+def test_golden_fixtures_exist():
+    assert len(GOLDEN) >= 3, "tests/golden/*.npz missing: run tests/golden/make_golden.py where /root/reference exists"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_golden_vectors_bit_exactly(path):
+    z = np.load(path)
+    n, ci, frames, stride = int(z["map_size"]), int(z["cascade"]), int(z["frames"]), int(z["row_stride"])
+    g = H.oracle_generator(n, [ci])
+    for _ in range(frames):
+        g.update_all(float(z["delta"]))
+    sub = max(stride, 8)
+    assert np.array_equal(g.spectrum(0)[::sub].view(np.uint32), z["spectrum_rows"].view(np.uint32))
+    assert np.array_equal(g.displacement(0)[::stride], z["displacement"])
+    assert np.array_equal(g.normal(0)[::stride], z["normal"])
+    # fft_buffer half 0 after the transpose, last frame (modulate -> rows -> transpose)
+    p = cascade_preset(ci)
+    x = O.spectrum_modulate(n, p["tile_length"], DEPTH, np.float32(g.params[0].time), g.spectrum(0))
+    half0 = O.fft_rows(n, O.fft_butterfly(n), x).transpose(0, 2, 1, 3)
+    assert np.array_equal(np.ascontiguousarray(half0[:, ::sub]).view(np.uint32), z["intermediate_rows"].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [8, 64, 256])
+def test_row_pass_is_unnormalised_inverse_dft(n):
+    """fft_butterfly.glsl + fft_compute.glsl == N * ifft along rows (independent NumPy FP64 check)"""
+    if n < 128:  # the oracle generalises to any power of two; the reference shaders start at 128
+        pass
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((4, n, n, 2)).astype(np.float32)
+    y = O.fft_rows(n, O.fft_butterfly(n), x)
+    ref = np.fft.ifft(x[..., 0].astype(np.float64) + 1j * x[..., 1], axis=2) * n
+    assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 1e-6
+
+
+def test_two_passes_are_the_transposed_ifft2():
+    """wave_generator.gd:77-82 skips the second transpose: result == (N^2 * ifft2(X))^T"""
+    n = 128
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, n, n, 2)).astype(np.float32)
+    y = O.ifft2(n, O.fft_butterfly(n), x)
+    X = x[..., 0].astype(np.float64) + 1j * x[..., 1]
+    ref = np.transpose(np.fft.ifft2(X, axes=(1, 2)) * n * n, (0, 2, 1))
+    assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 2e-6
+    assert H.relmax(y[..., 0] + 1j * y[..., 1], np.transpose(ref, (0, 2, 1))) > 0.1  # and NOT the untransposed one
+
+
+def test_half_conversion_is_ieee_rte():
+    rng = np.random.default_rng(9)
+    v = np.concatenate([rng.standard_normal(20000).astype(np.float32) * 4, np.float32([0, -0.0, 1e-8, 6e-8, 65504, 65520, 1e9, -1e9]),
+                        (rng.standard_normal(2000) * 1e-5).astype(np.float32)])
+    assert np.array_equal(O.f32_to_f16_bits(v), v.astype(np.float16).view(np.uint16))
