@@ -89,6 +89,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
+    from godotoceanwaves_amd import sharding
 
     n, C = args.map_size, args.cascades
     layers = max(2, C)
@@ -101,7 +102,7 @@ def main():
     gen.external_maps = (disp.data_ptr(), norm.data_ptr())
     gen.init_gpu(layers)
     # global cascade ids: rank r owns cascades r*C .. r*C+C-1 (independent units; presets repeat with new seeds)
-    params = [WaveCascadeParameters(**cascade_preset(rank * C + i)) for i in range(C)]
+    params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
 
     def sync_all():
         if world > 1:
@@ -110,13 +111,11 @@ def main():
 
     gathered = None
     if world > 1:
-        gathered = (torch.empty((world,) + tuple(disp.shape), dtype=disp.dtype, device="cuda"),
-                    torch.empty((world,) + tuple(norm.shape), dtype=norm.dtype, device="cuda"))
+        gathered = sharding.alloc_gather_buffers(torch, world, disp, norm)
 
     def gather():
         gen.sync()
-        dist.all_gather_into_tensor(gathered[0], disp)
-        dist.all_gather_into_tensor(gathered[1], norm)
+        sharding.gather_maps(dist, gathered, disp, norm)
 
     # ---- warm-up (includes the one-time spectrum generation) ----
     t_spec0 = time.perf_counter()
