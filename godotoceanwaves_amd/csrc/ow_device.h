@@ -602,10 +602,27 @@ struct Pass2 {
 #pragma unroll
         for (int j = 0; j < P; ++j) d[j] = gload8<AUX>(T_c, voff, t_soff(layer, rot(j)));
     }
-    // previous foam (FP16 bits of normal.a) of the lane's P output texels; tex = x'*N + t
-    static OW_DEV void load_foam(uint16_t *foam_prev, uint32_t tex, GBuf norm_c) {
+    // Foam state.  The reference re-reads normal_map.a (fft_unpack.glsl:61); reading 2 useful bytes out of every
+    // 8-byte texel would pull the whole normal map back in, so the context keeps a private FP16 copy of the foam
+    // channel in the order this kernel consumes it: foam[x'][t][o] = foam of texel (row x', col t + T*o), i.e. one
+    // lane's 16 values are 32 contiguous bytes (two 16-byte accesses instead of sixteen 2-byte ones, 2 B/texel
+    // read + 2 B/texel written instead of 8 B/texel read).  Same FP16 bits as normal.a, so the recurrence is
+    // unchanged.  pk[i] holds the halves of o = 2i (low) and 2i + 1 (high).
+    OW_HD static constexpr uint32_t foam_index(int xp, int yp) { return (uint32_t)xp * N + (uint32_t)(yp % T) * 16u + (uint32_t)(yp / T); }
+    static OW_DEV void load_foam(uint32_t *pk, int t, int xp, GBuf foam_c) {
+        const uint32_t voff = foam_index(xp, t) * 2u;
+        const f32x4 a = gload16(foam_c, voff, 0u), b = gload16(foam_c, voff, 16u);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int o = 0; o < P; ++o) foam_prev[o] = gload2(norm_c, tex * 8u + 6u, (uint32_t)(T * o) * 8u);
+        for (int i = 0; i < 8; ++i) pk[i] = __builtin_bit_cast(uint32_t, v[i]);
+    }
+    static OW_DEV void store_foam(const uint32_t *pk, int t, int xp, GBuf foam_c) {
+        const uint32_t voff = foam_index(xp, t) * 2u;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, pk[i]);
+        gstore16(foam_c, voff, 0u, f32x4{v[0], v[1], v[2], v[3]});
+        gstore16(foam_c, voff, 16u, f32x4{v[4], v[5], v[6], v[7]});
     }
 
     // optional FP32 debug image: 8 pre-quantisation channels per texel [hx,hy,hz,gx,gy,dhx_dx,foam,J]
@@ -620,8 +637,9 @@ struct Pass2 {
     // layer 2 done (fft_unpack.glsl:54): dhy_dz = re, dhx_dx = im of output ordinal o: OutMap<N>::slot_of(o) of d
     // (nothing to compute: the caller keeps the layer's registers)
     // layer 3 done (fft_unpack.glsl:55-66): Jacobian, foam RMW, gy; gy_foam[o] = packed halves (gy | foam << 16)
+    // foam_pk: in = previous foam halves, out = new foam halves (see load_foam)
     template <bool F32>
-    static OW_DEV void after_layer3(const cplx *l3, const cplx *l2, const uint16_t *foam_prev, uint32_t *gy_foam,
+    static OW_DEV void after_layer3(const cplx *l3, const cplx *l2, uint32_t *foam_pk, uint32_t *gy_foam,
                                     uint32_t tex, const CascadeFrame &cf, GBuf f32_c) {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
@@ -630,12 +648,14 @@ struct Pass2 {
             const float dhz_dz = l3[sl].x, dhz_dx = l3[sl].y;
             const float jac = (1.0f + dhx_dx) * (1.0f + dhz_dz) - dhz_dx * dhz_dx;
             const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
-            float foam = h2f(foam_prev[o]);
+            float foam = h2f((uint16_t)((foam_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu));
             foam = mul_rn(foam, cf.foam_decay);
             foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
             foam = fminf(fmaxf(foam, 0.0f), 1.0f);
             const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));  // 1-ulp reciprocal: far inside the FP16 output step
-            gy_foam[o] = (uint32_t)f2h(gy) | ((uint32_t)f2h(foam) << 16);
+            const uint32_t foam_h = f2h(foam);
+            gy_foam[o] = (uint32_t)f2h(gy) | (foam_h << 16);
+            foam_pk[o / 2] = (o & 1) ? ((foam_pk[o / 2] & 0xFFFFu) | (foam_h << 16)) : ((foam_pk[o / 2] & 0xFFFF0000u) | foam_h);
             if (F32) {
                 f32_put(f32_c, tex, o, 4, gy);
                 f32_put(f32_c, tex, o, 6, foam);

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
     const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
     const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
 
     float keep = 0.0f;
@@ -251,17 +252,18 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
         OW_STAMP(1, l2[0].x)
         if constexpr (kFft) row_ifft<N>(l2, t, lds_row, tw_lds);
         cplx l3[P];
-        uint16_t foam_prev[P];
+        uint32_t foam_pk[P / 2];
         fetch(l3, 3);
         if constexpr (kLoad) {
-            Pass2<N>::load_foam(foam_prev, tex, norm_c);
+            Pass2<N>::load_foam(foam_pk, t, xp, foam_c);
         } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) foam_prev[j] = 0;
+            for (int j = 0; j < P / 2; ++j) foam_pk[j] = 0;
         }
         if constexpr (kFft) row_ifft<N>(l3, t, lds_row, tw_lds);
         OW_STAMP(2, l3[0].x)
-        Pass2<N>::template after_layer3<F32 && kStore>(l3, l2, foam_prev, gy_foam, tex, cf, f32_c);
+        Pass2<N>::template after_layer3<F32 && kStore>(l3, l2, foam_pk, gy_foam, tex, cf, f32_c);
+        if (kStore || dbg.never_true) Pass2<N>::store_foam(foam_pk, t, xp, foam_c);
 #pragma unroll
         for (int o = 0; o < P; ++o) dhx_dx[o] = l2[OutMap<N>::slot_of(o)].y;
     }

@@ -12,6 +12,7 @@ struct DeviceBuffers {
     cplx *T;        // [layers][4 packed layers][N/16 y/16][N x'][16 y%16] complex: transposed intermediate
     u16x4 *disp;    // [layers][N][N] RGBA16F
     u16x4 *norm;    // [layers][N][N] RGBA16F (foam in .a)
+    uint16_t *foam; // [layers][N x'][N/16 t][16 o] FP16: private copy of normal.a in pass-2 lane order (Pass2::foam_index)
     float *f32;     // [layers][N][N][8] or nullptr
     const cplx *tw; // twiddle table (plan_tw_total(N) entries)
 };

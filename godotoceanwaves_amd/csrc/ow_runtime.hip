@@ -243,6 +243,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         OW_ALLOC(c->buf.norm, L * pl * sizeof(ow::u16x4));            // (:35)
         c->own_norm = true;
     }
+    OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
     if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
     std::vector<ow::cplx> tw;
     ow::make_twiddles(c->n, tw);
@@ -253,6 +254,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     if (hipMemcpyAsync(c->tw_dev, tw.data(), tw.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.norm, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.foam, 0, L * pl * sizeof(uint16_t), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::f32x4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -270,6 +272,7 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->buf.T);
     if (c->own_disp) (void)hipFree(c->buf.disp);
     if (c->own_norm) (void)hipFree(c->buf.norm);
+    (void)hipFree(c->buf.foam);
     (void)hipFree(c->buf.f32);
     (void)hipFree(c->tw_dev);
     for (auto &e : c->ev)
@@ -364,7 +367,15 @@ ow_status ow_set_normal_map(ow_context *c, int32_t cascade, const void *norm) {
     if (st != OW_OK) return st;
     if (!norm) return fail(OW_ERR_INVALID, "null normal map");
     OW_HIP(hipSetDevice(c->device));
+    // the foam channel (.a) also goes into the context's private FP16 foam plane, in pass-2 lane order
+    // (ow_device.h Pass2::foam_index): that plane, not normal.a, is what the recurrence reads back
+    const size_t n = (size_t)c->n, tl = n / 16;
+    std::vector<uint16_t> foam(plane(c));
+    const uint16_t *src = static_cast<const uint16_t *>(norm);
+    for (size_t xp = 0; xp < n; ++xp)
+        for (size_t yp = 0; yp < n; ++yp) foam[xp * n + (yp % tl) * 16 + yp / tl] = src[(xp * n + yp) * 4 + 3];
     OW_HIP(hipMemcpyAsync(c->buf.norm + cascade * plane(c), norm, plane(c) * sizeof(ow::u16x4), hipMemcpyHostToDevice, c->stream));
+    OW_HIP(hipMemcpyAsync(c->buf.foam + cascade * plane(c), foam.data(), plane(c) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
     return OW_OK;
 }

@@ -130,8 +130,11 @@ ow_status ow_get_device_ptrs(ow_context *ctx, void **displacement_map, void **no
  * (row-major, 8 bytes per texel, N*N*8 bytes each).  Either pointer may be NULL.  Synchronises. */
 ow_status ow_get_maps(ow_context *ctx, int32_t cascade, void *displacement_rgba16f, void *normal_rgba16f);
 
-/* Foam / simulation state: the only persistent state besides `time` is the normal map (foam = .a,
- * FP16).  ow_set_normal_map uploads N*N*8 bytes into one layer (checkpoint/restore, re-sharding). */
+/* Foam / simulation state: the only persistent state besides `time` is the foam channel (normal.a, FP16,
+ * fft_unpack.glsl:61-64).  The context keeps the bits the recurrence re-reads in a private FP16 plane (same
+ * values as normal.a), so restoring state MUST go through ow_set_normal_map, which uploads N*N*8 bytes into one
+ * layer and refreshes that plane (checkpoint/restore, re-sharding); writing into the normal map through the
+ * device pointer does not change the simulation. */
 ow_status ow_set_normal_map(ow_context *ctx, int32_t cascade, const void *normal_rgba16f);
 
 /* ---- parity / debug ------------------------------------------------------------------------------ */

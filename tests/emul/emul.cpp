@@ -63,12 +63,12 @@ void rows_fft(const float *in, float *out, int rows) {
 }
 
 template <int N>
-void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, float *f32) {
+void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
     constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const uint32_t plane = (uint32_t)N * N;
     const GBuf h0_c = make_gbuf(h0, plane * 16u), om_c = make_gbuf(omega, plane * 4u), T_c = make_gbuf(Tbuf, t_cascade_bytes(N));
-    const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), f32_c = make_gbuf(f32, plane * 32u);
+    const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), foam_c = make_gbuf(foam, plane * 2u), f32_c = make_gbuf(f32, plane * 32u);
     Block<N, NT> w;
     // ---- pass 1 (mirrors k_pass1) ----
     {
@@ -100,7 +100,7 @@ void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, ui
         static cplx l2[NT][P], l3[NT][P], l1[NT][P], l0[NT][P];
         static float dhx_dx[NT][P], hz[NT][P];
         static uint32_t gy_foam[NT][P];
-        static uint16_t foam_prev[NT][P];
+        static uint32_t foam_pk[NT][P / 2];
         for (int row0 = 0; row0 < N; row0 += kWgRows) {
             auto xp_of = [&](int l) { return row0 + l / Tn; };
             auto tex_of = [&](int l) { return (uint32_t)(xp_of(l) * N + l % Tn); };
@@ -108,12 +108,13 @@ void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, ui
             w.row_ifft(l2);
             for (int l = 0; l < NT; ++l) {
                 Pass2<N>::template load_layer<0>(l3[l], l % Tn, xp_of(l), 3, T_c);
-                Pass2<N>::load_foam(foam_prev[l], tex_of(l), norm_c);
+                Pass2<N>::load_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
             }
             w.row_ifft(l3);
             for (int l = 0; l < NT; ++l) {
-                if (f32) Pass2<N>::template after_layer3<true>(l3[l], l2[l], foam_prev[l], gy_foam[l], tex_of(l), cf, f32_c);
-                else Pass2<N>::template after_layer3<false>(l3[l], l2[l], foam_prev[l], gy_foam[l], tex_of(l), cf, f32_c);
+                if (f32) Pass2<N>::template after_layer3<true>(l3[l], l2[l], foam_pk[l], gy_foam[l], tex_of(l), cf, f32_c);
+                else Pass2<N>::template after_layer3<false>(l3[l], l2[l], foam_pk[l], gy_foam[l], tex_of(l), cf, f32_c);
+                Pass2<N>::store_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
                 for (int o = 0; o < P; ++o) dhx_dx[l][o] = l2[l][OutMap<N>::slot_of(o)].y;
             }
             for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(l1[l], l % Tn, xp_of(l), 1, T_c);
@@ -158,15 +159,16 @@ void emul_spectrum(int n, const SpectrumPC *pc, float *h0, float *omega) {
         }
 }
 
-// one frame of one cascade: Tbuf = 4*n*n*2 floats (device layout, see t_unit), norm is read (foam) and rewritten
+// one frame of one cascade: Tbuf = 4*n*n*2 floats (device layout, see t_unit); foam = n*n halves (device layout,
+// Pass2::foam_index) is the recurrent state, read and rewritten; norm is written
 int emul_frame(int n, const float *h0, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
-               uint16_t *norm, float *f32) {
+               uint16_t *norm, uint16_t *foam, float *f32) {
     switch (n) {
-        case 128: frame<128>(h0, omega, *cf, Tbuf, disp, norm, f32); return 0;
-        case 256: frame<256>(h0, omega, *cf, Tbuf, disp, norm, f32); return 0;
-        case 512: frame<512>(h0, omega, *cf, Tbuf, disp, norm, f32); return 0;
-        case 1024: frame<1024>(h0, omega, *cf, Tbuf, disp, norm, f32); return 0;
-        case 2048: frame<2048>(h0, omega, *cf, Tbuf, disp, norm, f32); return 0;
+        case 128: frame<128>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 256: frame<256>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 512: frame<512>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 1024: frame<1024>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 2048: frame<2048>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
     }
     return 1;
 }

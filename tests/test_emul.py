@@ -38,7 +38,7 @@ def emul():
     u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
     E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
     E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p]
-    E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, f32p]
+    E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
     return E
 
@@ -79,6 +79,7 @@ def test_emulated_kernels_match_oracle(emul, n, ci):
 
     g = H.oracle_generator(n, [ci])
     norm = np.zeros((n, n, 4), np.uint16)
+    foam = np.zeros((n * n,), np.uint16)  # the context's private FP16 foam plane (device order)
     for frame in range(3):
         g.update_all(UPDATE_DELTA)
         P = g.params[0]
@@ -86,7 +87,7 @@ def test_emulated_kernels_match_oracle(emul, n, ci):
                 np.exp(-np.float32(P.foam_decay_rate), dtype=np.float32), 0, 0)
         T = np.zeros((n * n * 4 * 2,), np.float32)
         disp, f32 = np.zeros((n, n, 4), np.uint16), np.zeros((n, n, 8), np.float32)
-        assert emul.emul_frame(n, h0, om, C.byref(cf), T, disp, norm, f32) == 0
+        assert emul.emul_frame(n, h0, om, C.byref(cf), T, disp, norm, foam, f32) == 0
         ref = g.f32(0)
         for c, name in enumerate(H.CHANNELS):
             if name == "foam":
