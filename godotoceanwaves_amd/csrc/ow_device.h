@@ -48,6 +48,17 @@ struct alignas(8) u16x4 {
     uint16_t x, y, z, w;
 };
 
+// LDS read of one complex.  On the device the access is volatile in the LDS address space: the compiler then
+// emits one ds_read_b64 per value (256 B/clk) instead of pairing them into ds_read2_b64 (128 B/clk).
+OW_DEV cplx lds_read(const cplx *p) {
+#if OW_DEVICE_BUILD
+    typedef __attribute__((address_space(3))) cplx lds_cplx;
+    return *(const volatile lds_cplx *)p;
+#else
+    return *p;
+#endif
+}
+
 constexpr float kPi = 3.141592653589793f;  // GLSL `#define PI` is an FP32 literal
 constexpr float kG = 9.81f;                // GLSL `#define G`
 constexpr int kLayers = 4;                 // NUM_SPECTRA (spectrum_modulate.glsl:14)
@@ -207,7 +218,7 @@ OW_DEV void fft_stage_compute(cplx *d, int t, const cplx *__restrict__ tw) {
             const int p = (t + T * b) / s;
 #pragma unroll
             for (int k = 1; k < R; ++k) {
-                d[b * R + dft_pos(R, k)] = cmul(d[b * R + dft_pos(R, k)], twj[(k - 1) * m + p]);
+                d[b * R + dft_pos(R, k)] = cmul(d[b * R + dft_pos(R, k)], lds_read(twj + (k - 1) * m + p));
                 if (k % 5 == 0) OW_SCHED_FENCE();  // a few table reads in flight at a time, not all 15
             }
         }
@@ -250,9 +261,84 @@ OW_DEV void fft_stage_read(cplx *d, int t, const cplx *lds_row) {
 #pragma unroll
     for (int b = 0; b < B; ++b) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) d[b * R + i] = base[rd_slot<N, J>(0, b, i) - rd_slot<N, J>(0, 0, 0)];
+        for (int i = 0; i < R; ++i) d[b * R + i] = lds_read(base + (rd_slot<N, J>(0, b, i) - rd_slot<N, J>(0, 0, 0)));
     }
 }
+
+// Exchange between stage 1 and the last stage WITHOUT LDS, for N = 512 and 1024 (a row inside one wave).
+// After stage 1, lane (q = t%16, p = t/16) holds output k of its radix-16 butterfly = element q + 256*p + 16*k;
+// the last stage (radix R2 = N/256) wants, in lane (q, r) and butterfly b, the R2 elements q + 16*r + 64*b... i.e.
+// with k = R2*b + r:  (lane row p, register k)  ->  (lane row r, input p of butterfly b).  For every b that is an
+// R2 x R2 transpose between the 16-lane row index and the register index, done with the gfx950 row-swap
+// instructions (v_permlane32_swap: upper 32 lanes of A <-> lower 32 lanes of B; v_permlane16_swap: odd 16-lane
+// rows of A <-> even rows of B) on the VALU of the wave's own SIMD instead of through the CU-wide LDS pipe.
+constexpr bool plan_lane_exchange(int N) { return N == 512 || N == 1024; }
+#if OW_DEVICE_BUILD
+OW_DEV void swap_rows32(cplx &a, cplx &b) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    // (element values are copied to scalars first: bit-casting the vector-element lvalue directly miscompiles)
+    const float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    const u2 rx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ax), __builtin_bit_cast(uint32_t, bx), false, false);
+    const u2 ry = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ay), __builtin_bit_cast(uint32_t, by), false, false);
+    const uint32_t nax = rx.x, nbx = rx.y, nay = ry.x, nby = ry.y;
+    a = cplx{__builtin_bit_cast(float, nax), __builtin_bit_cast(float, nay)};
+    b = cplx{__builtin_bit_cast(float, nbx), __builtin_bit_cast(float, nby)};
+}
+OW_DEV void swap_rows16(cplx &a, cplx &b) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    // (element values are copied to scalars first: bit-casting the vector-element lvalue directly miscompiles)
+    const float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    const u2 rx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ax), __builtin_bit_cast(uint32_t, bx), false, false);
+    const u2 ry = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ay), __builtin_bit_cast(uint32_t, by), false, false);
+    const uint32_t nax = rx.x, nbx = rx.y, nay = ry.x, nby = ry.y;
+    a = cplx{__builtin_bit_cast(float, nax), __builtin_bit_cast(float, nay)};
+    b = cplx{__builtin_bit_cast(float, nbx), __builtin_bit_cast(float, nby)};
+}
+#endif
+// Order of the swaps and the final renaming, shared by the device code and the 64-lane CPU emulation: SW32 / SW16
+// are called as SW(slot_a, slot_b) for whole-wave registers.
+template <int N, class SW32, class SW16, class MOVE>
+OW_HD void lane_exchange_plan(SW32 sw32, SW16 sw16, MOVE move) {
+    constexpr int R2 = plan_R(N, 2), NB = 16 / R2;
+    for (int b = 0; b < NB; ++b) {
+        int X[4];
+        for (int r = 0; r < R2; ++r) X[r] = dft_pos(16, R2 * b + r);
+        if (R2 == 4) {
+            sw32(X[0], X[2]);
+            sw32(X[1], X[3]);
+            sw16(X[0], X[1]);
+            sw16(X[2], X[3]);
+        } else {
+            sw16(X[0], X[1]);
+        }
+        for (int p = 0; p < R2; ++p) move(b * R2 + p, X[p]);  // last-stage input p of butterfly b <- register X_p
+    }
+}
+#if OW_DEVICE_BUILD
+template <int N>
+OW_DEV void fft_lane_exchange(cplx *d) {
+    constexpr int R2 = plan_R(N, 2), NB = 16 / R2;
+    cplx o[kP];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        cplx *X[4];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) X[r] = d + dft_pos(16, R2 * b + r);
+        if constexpr (R2 == 4) {
+            swap_rows32(*X[0], *X[2]);
+            swap_rows32(*X[1], *X[3]);
+            swap_rows16(*X[0], *X[1]);
+            swap_rows16(*X[2], *X[3]);
+        } else {
+            swap_rows16(*X[0], *X[1]);
+        }
+#pragma unroll
+        for (int p = 0; p < R2; ++p) o[b * R2 + p] = *X[p];
+    }
+#pragma unroll
+    for (int j = 0; j < kP; ++j) d[j] = o[j];
+}
+#endif
 
 // element index carried by register slot j before stage 0: t + T*j  (N/16 == T)
 template <int N>
@@ -569,7 +655,7 @@ struct Pass1 {
         const uint32_t voff = t_unit(N, 0, xi, row0 + q) * 8u;
         cplx v[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = st[xi + T * k];
+        for (int k = 0; k < P; ++k) v[k] = lds_read(st + xi + T * k);
 #pragma unroll
         for (int k = 0; k < P; ++k) gstore8<AUX>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * k, 0)) * 8u, v[k]);
     }

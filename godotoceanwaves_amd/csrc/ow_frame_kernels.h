@@ -80,10 +80,14 @@ __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cp
     row_sync<N>();
     fft_stage_compute<N, 1>(d, t, tw);
     if constexpr (plan_S(N) == 3) {
-        fft_stage_write<N, 1>(d, t, lds_row);
-        row_sync<N>();
-        fft_stage_read<N, 2>(d, t, lds_row);
-        row_sync<N>();
+        if constexpr (plan_lane_exchange(N)) {
+            fft_lane_exchange<N>(d);  // row-swap instructions, no LDS
+        } else {
+            fft_stage_write<N, 1>(d, t, lds_row);
+            row_sync<N>();
+            fft_stage_read<N, 2>(d, t, lds_row);
+            row_sync<N>();
+        }
         fft_stage_compute<N, 2>(d, t, tw);
     }
 }

@@ -4,6 +4,7 @@
 // HIP kernels be checked against the oracle on a machine without a GPU.  Never shipped, never linked
 // into libocean_waves.so.
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "ow_device.h"
@@ -30,8 +31,29 @@ struct Block {
         for (int l = 0; l < NT; ++l) fft_stage_read<N, 1>(d[l], l % Tn, row(l));
         for (int l = 0; l < NT; ++l) fft_stage_compute<N, 1>(d[l], l % Tn, tw.data());
         if constexpr (plan_S(N) == 3) {
-            for (int l = 0; l < NT; ++l) fft_stage_write<N, 1>(d[l], l % Tn, row(l));
-            for (int l = 0; l < NT; ++l) fft_stage_read<N, 2>(d[l], l % Tn, row(l));
+            if constexpr (plan_lane_exchange(N)) {
+                // 64-lane emulation of fft_lane_exchange: the same swap plan, wave by wave
+                for (int w0 = 0; w0 < NT; w0 += 64) {
+                    cplx(*w)[P] = d + w0;
+                    cplx o[64][P];
+                    lane_exchange_plan<N>(
+                        [&](int a, int b) {  // v_permlane32_swap: lanes 32..63 of A <-> lanes 0..31 of B
+                            for (int l = 0; l < 32; ++l) std::swap(w[32 + l][a], w[l][b]);
+                        },
+                        [&](int a, int b) {  // v_permlane16_swap: odd 16-lane rows of A <-> even rows of B
+                            for (int rw = 0; rw < 2; ++rw)
+                                for (int l = 0; l < 16; ++l) std::swap(w[32 * rw + 16 + l][a], w[32 * rw + l][b]);
+                        },
+                        [&](int dst, int src) {
+                            for (int l = 0; l < 64; ++l) o[l][dst] = w[l][src];
+                        });
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < P; ++j) w[l][j] = o[l][j];
+                }
+            } else {
+                for (int l = 0; l < NT; ++l) fft_stage_write<N, 1>(d[l], l % Tn, row(l));
+                for (int l = 0; l < NT; ++l) fft_stage_read<N, 2>(d[l], l % Tn, row(l));
+            }
             for (int l = 0; l < NT; ++l) fft_stage_compute<N, 2>(d[l], l % Tn, tw.data());
         }
     }

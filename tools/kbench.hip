@@ -67,6 +67,30 @@ int main(int argc, char **argv) {
     RUNP1(0, 0) RUNP1(2, 0) RUNP1(0, 2) RUNP1(2, 2) RUNP1(1, 0) RUNP1(3, 0)
     RUNP2(0, 0) RUNP2(2, 0) RUNP2(0, 2) RUNP2(2, 2) RUNP2(1, 0) RUNP2(0, 1) RUNP2(0, 3)
     TICK(0, 0, 0, 0) TICK(0, 0, 2, 2) TICK(0, 0, 0, 2) TICK(0, 2, 0, 2) TICK(0, 2, 2, 2) TICK(2, 0, 2, 2) TICK(1, 0, 1, 2)
+    {   // two-stream experiment: pass 2 of tick n (reads T) next to pass 1 of tick n+1 (writes a second T), dependencies as in a real pipeline
+        DeviceBuffers bufB = buf; CK(hipMalloc((void**)&bufB.T, L * pl * 32)); CK(hipMemset(bufB.T, 0, L * pl * 32));
+        hipStream_t s2; CK(hipStreamCreate(&s2));
+        const int K = iters; std::vector<hipEvent_t> e1(K + 2), e2(K + 2);
+        for (auto &e : e1) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); for (auto &e : e2) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipDeviceSynchronize());
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            CK(hipEventRecord(a, s));
+            CK(hipStreamWaitEvent(s2, a, 0));
+            for (int i = 0; i < K; ++i) {
+                DeviceBuffers &bi = (i & 1) ? bufB : buf;
+                if (i >= 2) CK(hipStreamWaitEvent(s2, e2[i - 2], 0));           // T buffer of tick i is free once pass 2 of tick i-2 has read it
+                hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s2, bi, args, dbg);
+                CK(hipEventRecord(e1[i], s2));
+                CK(hipStreamWaitEvent(s, e1[i], 0));
+                hipLaunchKernelGGL((k_pass2<N, false, 0>), dim3(blocks2), dim3(thr2), 0, s, bi, args, dbg);
+                CK(hipEventRecord(e2[i], s));
+            }
+            CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipStreamSynchronize(s2));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            printf("two-stream pipelined tick : %8.2f us\n", ms / K * 1e3f);
+        }
+    }
     // both passes back to back (a tick)
     printf("tick        : %8.2f us\n", time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
                                                       hipLaunchKernelGGL((k_pass2<N, false, 0>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }, iters, s));
