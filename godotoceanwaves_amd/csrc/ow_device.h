@@ -588,22 +588,50 @@ struct Pass1 {
     static constexpr int rot(int j) { return (j + 8) & 15; }
 
     // h[j] = h(k, t) = h0 * m + conj(h0(-k)) * conj(m),  m = exp(i * omega * time)   (spectrum_modulate.glsl:64-68)
-    // for the lane's texels x = t + T*rot(j) of row y; tex = y*N + t (texel index of the lane's first point)
+    // for the lane's texels x = t + T*rot(j) of row y.
+    //
+    // The reference's spectrum texel stores (h0(k), conj(h0(-k))) -- every amplitude twice.  Here only the plane
+    // a[y][x] = h0(k) is kept (8 B/texel): the partner comes from the mirrored texel, zw = conj(a[(N-y)%N][(N-x)%N])
+    // (spectrum_compute.glsl:121-124 evaluates exactly that), and omega is even in k, so rows beyond N/2 read
+    // the mirrored row of the omega plane as well.  The block that owns the mirrored rows runs on the same XCD at
+    // the same time (p1_block_to_rows), reads the same lines, and the XCD's L2 serves one of the two: HBM sees each
+    // amplitude once per tick (8 + 2 B/texel instead of 16 + 4).
+    // a_off / b_off: byte offsets of a[y][t] and of the mirrored texel of (t, slot 0 of the natural order);
+    // b_wrap: lane 0 of a row pairs x = 0 with x = 0 (not with x = N).
     template <int AUX = 0>
-    static OW_DEV void load_modulate(cplx *h, uint32_t tex, GBuf h0_c, GBuf om_c, float time) {
-        f32x4 v[P];
+    static OW_DEV void load_modulate(cplx *h, int t, int y, GBuf h0_c, GBuf om_c, float time) {
+        const int ym = (N - y) % N;
+        const int tm = (T - t) % T;                           // lane part of the mirrored column
+        const uint32_t a_off = (uint32_t)(y * N + t) * 8u;
+        const uint32_t b_off = (uint32_t)(ym * N + tm) * 8u;  // + block part below
+        const bool lane0 = (t == 0);
+        // omega: own row for y <= N/2, else the mirrored row (same values, shared lines)
+        const bool om_mirror = y > N / 2;
+        const uint32_t o_off = (om_mirror ? (uint32_t)(ym * N + tm) : (uint32_t)(y * N + t)) * 4u;
+        cplx a[P], b[P];
         float om[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            v[j] = gload16<AUX>(h0_c, tex * 16u, (uint32_t)(T * rot(j)) * 16u);
-            om[j] = gload4<AUX>(om_c, tex * 4u, (uint32_t)(T * rot(j)) * 4u);
+            const int blk = rot(j);  // x = t + T*blk ;  mirrored x = (T - t) + T*(15 - blk)  [t > 0],  T*((16 - blk) % 16)  [t = 0]
+            a[j] = gload8<AUX>(h0_c, a_off, (uint32_t)(T * blk) * 8u);
+            const uint32_t mb = (uint32_t)(T * (15 - blk)), mb0 = (uint32_t)(T * ((16 - blk) % 16));
+            if (blk == 0) {  // lane 0 needs block 0 here, the other lanes block 15: one lane-dependent offset
+                b[j] = gload8<AUX>(h0_c, lane0 ? b_off : b_off + mb * 8u, 0u);
+                om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off : o_off + mb * 4u, 0u) : gload4<AUX>(om_c, o_off, 0u);
+            } else {
+                b[j] = gload8<AUX>(h0_c, lane0 ? b_off + (uint32_t)T * 8u : b_off, mb * 8u);
+                (void)mb0;
+                om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off + (uint32_t)T * 4u : o_off, mb * 4u)
+                                  : gload4<AUX>(om_c, o_off, (uint32_t)(T * blk) * 4u);
+            }
         }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             float sn, cs;
             sincos_phase(mul_rn(om[j], time), sn, cs);
-            const float ar = v[j].x * cs - v[j].y * sn, ai = v[j].x * sn + v[j].y * cs;
-            const float br = v[j].z * cs + v[j].w * sn, bi = v[j].w * cs - v[j].z * sn;
+            const f32x4 v = f32x4{a[j].x, a[j].y, b[j].x, -b[j].y};  // the reference's texel (h0(k), conj(h0(-k)))
+            const float ar = v.x * cs - v.y * sn, ai = v.x * sn + v.y * cs;
+            const float br = v.z * cs + v.w * sn, bi = v.w * cs - v.z * sn;
             h[j] = cplx{ar + br, ai + bi};
             opaque_inplace(h[j]);
             if (j % 4 == 3) OW_SCHED_FENCE();
@@ -857,7 +885,9 @@ OW_DEV cplx spectrum_amplitude(int idx, int idy, int n, const SpectrumPC &pc) { 
     return cplx{rr * cosf(th) * amp, rr * sinf(th) * amp};
 }
 
-OW_DEV f32x4 spectrum_texel(int x, int y, int n, const SpectrumPC &pc) {  // spectrum_compute.glsl:117-125
+// The reference texel (spectrum_compute.glsl:117-125) is (amplitude(id), conj(amplitude(mod(-id, dims)))); only
+// the first half is stored (plane a[y][x]), the second half IS the first half of the mirrored texel (Pass1).
+OW_DEV f32x4 spectrum_texel(int x, int y, int n, const SpectrumPC &pc) {
     const cplx a = spectrum_amplitude(x, y, n, pc);
     const cplx b = spectrum_amplitude((n - x) % n, (n - y) % n, n, pc);
     return f32x4{a.x, a.y, b.x, -b.y};

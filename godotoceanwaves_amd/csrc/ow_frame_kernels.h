@@ -92,15 +92,28 @@ __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cp
     }
 }
 
-// Pass-1 block -> (launch slot, first row).  The two blocks that write the two 64-byte halves of the same
-// 128-byte lines of T (rows 16g..16g+7 and 16g+8..16g+15) get block indices b and b+8: the dispatcher places
-// block b on XCD b % 8, so both halves meet in the same L2 before they are written back (speed only).
+// Pass-1 block -> (launch slot, first row).  Two things are arranged through the block index, both for speed only
+// (the dispatcher places block b on XCD b % 8; nothing depends on it for correctness):
+//  * the two blocks that write the two 64-byte halves of the same 128-byte lines of T (rows 16g..16g+7 and
+//    16g+8..16g+15) are neighbours on one XCD, so the halves meet in one L2 before they are written back;
+//  * the 16-row group g and its mirror group N/16-1-g (rows N-y) are on the same XCD next to each other: both
+//    read the same h0 / omega lines (Pass1::load_modulate) and the XCD's L2 fetches them from HBM once.
 template <int N>
 __device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
+    constexpr int G = N / 16;  // 16-row groups per cascade; 2*G blocks per cascade
     const int b = blockIdx.x, x = b & 7, i = b >> 3;
-    const int grow = (x + 8 * (i >> 1)) * 16 + (i & 1) * 8;  // row index over all launch slots
-    slot = grow / N;
-    row0 = grow % N;
+    if constexpr (G >= 16) {
+        constexpr int PER = G / 4;  // blocks per XCD per cascade: G/16 mirror pairs x 2 groups x 2 halves
+        slot = i / PER;
+        const int j = i % PER;
+        const int pair = x + 8 * (j >> 2);
+        const int g = ((j >> 1) & 1) ? G - 1 - pair : pair;
+        row0 = g * 16 + (j & 1) * 8;
+    } else {  // N = 128: 8 groups only
+        const int grow = (x + 8 * (i >> 1)) * 16 + (i & 1) * 8;  // row index over all launch slots
+        slot = grow / N;
+        row0 = grow % N;
+    }
 }
 template <int N>
 __device__ __forceinline__ void p2_block_to_rows(int &slot, int &row0) {
@@ -150,13 +163,13 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     }
     const CascadeFrame cf = args.c[slot];
     const int y = row0 + rw;
-    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 16u);
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
     const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
 
     cplx h[P];
     if constexpr (kLoad) {
-        Pass1<N>::template load_modulate<AUX_H>(h, (uint32_t)(y * N + t), h0_c, om_c, cf.time);
+        Pass1<N>::template load_modulate<AUX_H>(h, t, y, h0_c, om_c, cf.time);
     } else {
 #pragma unroll
         for (int j = 0; j < P; ++j) h[j] = cplx{(float)(t + j) * 1e-3f + cf.time, (float)(t - j) * 1e-3f};

@@ -7,7 +7,8 @@
 namespace ow {
 
 struct DeviceBuffers {
-    f32x4 *h0;      // [layers][N][N] float4   (the `spectrum` texture, wave_generator.gd:31)
+    cplx *h0;       // [layers][N][N] complex h0(k): first half of the `spectrum` texel (wave_generator.gd:31); the second half,
+                    // conj(h0(-k)), is the mirrored texel of the same plane (Pass1::load_modulate)
     float *omega;   // [layers][N][N]          FP32 dispersion plane
     cplx *T;        // [layers][4 packed layers][N/16 y/16][N x'][16 y%16] complex: transposed intermediate
     u16x4 *disp;    // [layers][N][N] RGBA16F

@@ -228,7 +228,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
 #define OW_ALLOC(ptr, bytes)                                                                              \
     if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess)                                                \
         return bail(fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #ptr, (size_t)(bytes)));
-    OW_ALLOC(c->buf.h0, L * pl * sizeof(ow::f32x4));                  // spectrum (R32G32B32A32_SFLOAT, :31)
+    OW_ALLOC(c->buf.h0, L * pl * sizeof(ow::cplx));                   // h0(k): the non-redundant half of the spectrum texture (:31)
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     OW_ALLOC(c->buf.T, L * pl * ow::kLayers * sizeof(ow::cplx));  // half of the reference's fft_buffer (:33)
     if (cfg->displacement_map) {
@@ -255,7 +255,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.norm, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.foam, 0, L * pl * sizeof(uint16_t), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::f32x4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::cplx), c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "initial upload failed: %s", hipGetErrorString(hipGetLastError())));
@@ -395,9 +395,25 @@ ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omeg
     ow_status st = check_cascade(c, cascade);
     if (st != OW_OK) return st;
     OW_HIP(hipSetDevice(c->device));
-    if (h0) OW_HIP(hipMemcpyAsync(h0, c->buf.h0 + cascade * plane(c), plane(c) * sizeof(ow::f32x4), hipMemcpyDeviceToHost, c->stream));
+    std::vector<ow::cplx> a;
+    if (h0) {
+        a.resize(plane(c));
+        OW_HIP(hipMemcpyAsync(a.data(), c->buf.h0 + cascade * plane(c), plane(c) * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
+    }
     if (omega) OW_HIP(hipMemcpyAsync(omega, c->buf.omega + cascade * plane(c), plane(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
+    if (h0) {  // rebuild the reference's texel (h0(k), conj(h0(-k))) from the stored half (spectrum_compute.glsl:121-124)
+        const size_t n = (size_t)c->n;
+        for (size_t y = 0; y < n; ++y)
+            for (size_t x = 0; x < n; ++x) {
+                const ow::cplx v = a[y * n + x], m = a[((n - y) % n) * n + (n - x) % n];
+                float *o = h0 + (y * n + x) * 4;
+                o[0] = v.x;
+                o[1] = v.y;
+                o[2] = m.x;
+                o[3] = -m.y;
+            }
+    }
     return OW_OK;
 }
 

@@ -85,11 +85,11 @@ void rows_fft(const float *in, float *out, int rows) {
 }
 
 template <int N>
-void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
+void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
     constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const uint32_t plane = (uint32_t)N * N;
-    const GBuf h0_c = make_gbuf(h0, plane * 16u), om_c = make_gbuf(omega, plane * 4u), T_c = make_gbuf(Tbuf, t_cascade_bytes(N));
+    const GBuf h0_c = make_gbuf(h0a, plane * 8u), om_c = make_gbuf(omega, plane * 4u), T_c = make_gbuf(Tbuf, t_cascade_bytes(N));
     const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), foam_c = make_gbuf(foam, plane * 2u), f32_c = make_gbuf(f32, plane * 32u);
     Block<N, NT> w;
     // ---- pass 1 (mirrors k_pass1) ----
@@ -98,7 +98,7 @@ void frame(const float *h0, const float *omega, CascadeFrame cf, float *Tbuf, ui
         for (int row0 = 0; row0 < N; row0 += kWgRows) {
             for (int l = 0; l < NT; ++l) {
                 const int y = row0 + l / Tn, t = l % Tn;
-                Pass1<N>::load_modulate(h[l], (uint32_t)(y * N + t), h0_c, om_c, cf.time);
+                Pass1<N>::load_modulate(h[l], t, y, h0_c, om_c, cf.time);
             }
             for (int L = 0; L < kLayers; ++L) {
                 for (int l = 0; l < NT; ++l) {
@@ -171,26 +171,30 @@ int emul_rows_fft(int n, const float *in, float *out, int rows) {
     return 1;
 }
 
-void emul_spectrum(int n, const SpectrumPC *pc, float *h0, float *omega) {
+// h0 = the reference's float4 texels (for the comparison with the oracle), h0a = the plane the device stores (.xy only)
+void emul_spectrum(int n, const SpectrumPC *pc, float *h0, float *h0a, float *omega) {
     for (int y = 0; y < n; ++y)
         for (int x = 0; x < n; ++x) {
             const f32x4 v = spectrum_texel(x, y, n, *pc);
             float *o = h0 + ((size_t)y * n + x) * 4;
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+            const cplx a = spectrum_amplitude(x, y, n, *pc);
+            h0a[((size_t)y * n + x) * 2] = a.x;
+            h0a[((size_t)y * n + x) * 2 + 1] = a.y;
             omega[(size_t)y * n + x] = omega_texel(x, y, n, pc->tile_x, pc->tile_y, pc->depth);
         }
 }
 
-// one frame of one cascade: Tbuf = 4*n*n*2 floats (device layout, see t_unit); foam = n*n halves (device layout,
+// one frame of one cascade: h0 = the stored half-spectrum plane (n*n complex); Tbuf = 4*n*n*2 floats (device layout, see t_unit); foam = n*n halves (device layout,
 // Pass2::foam_index) is the recurrent state, read and rewritten; norm is written
-int emul_frame(int n, const float *h0, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
+int emul_frame(int n, const float *h0a, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
                uint16_t *norm, uint16_t *foam, float *f32) {
     switch (n) {
-        case 128: frame<128>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
-        case 256: frame<256>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
-        case 512: frame<512>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
-        case 1024: frame<1024>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
-        case 2048: frame<2048>(h0, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 128: frame<128>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 256: frame<256>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 512: frame<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 1024: frame<1024>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 2048: frame<2048>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
     }
     return 1;
 }

@@ -37,7 +37,7 @@ def emul():
     f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
     u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
     E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
-    E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p]
+    E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p, f32p]
     E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
     return E
@@ -71,8 +71,8 @@ def test_emulated_kernels_match_oracle(emul, n, ci):
     pc = H.spectrum_pc(p)
     epc = PC(p["spectrum_seed"][0], p["spectrum_seed"][1], p["tile_length"][0], p["tile_length"][1], pc.alpha, pc.peak_frequency,
              pc.wind_speed, pc.angle, DEPTH, p["swell"], p["detail"], p["spread"])
-    h0, om = np.zeros((n, n, 4), np.float32), np.zeros((n, n), np.float32)
-    emul.emul_spectrum(n, C.byref(epc), h0, om)
+    h0, h0a, om = np.zeros((n, n, 4), np.float32), np.zeros((n, n, 2), np.float32), np.zeros((n, n), np.float32)
+    emul.emul_spectrum(n, C.byref(epc), h0, h0a, om)
     # same libm on both sides + contraction off => the one-time spectrum and omega are BIT-identical
     assert np.array_equal(h0, O.spectrum_compute(n, pc))
     assert np.array_equal(om, O.omega(n, p["tile_length"], DEPTH))
@@ -87,7 +87,7 @@ def test_emulated_kernels_match_oracle(emul, n, ci):
                 np.exp(-np.float32(P.foam_decay_rate), dtype=np.float32), 0, 0)
         T = np.zeros((n * n * 4 * 2,), np.float32)
         disp, f32 = np.zeros((n, n, 4), np.uint16), np.zeros((n, n, 8), np.float32)
-        assert emul.emul_frame(n, h0, om, C.byref(cf), T, disp, norm, foam, f32) == 0
+        assert emul.emul_frame(n, h0a, om, C.byref(cf), T, disp, norm, foam, f32) == 0
         ref = g.f32(0)
         for c, name in enumerate(H.CHANNELS):
             if name == "foam":

@@ -29,12 +29,12 @@ int main(int argc, char **argv) {
     const int C = argc > 1 ? atoi(argv[1]) : 4;
     const size_t pl = (size_t)N * N, L = C;
     DeviceBuffers buf{};
-    CK(hipMalloc(&buf.h0, L * pl * 16)); CK(hipMalloc(&buf.omega, L * pl * 4)); CK(hipMalloc((void**)&buf.T, L * pl * 32));
+    CK(hipMalloc((void**)&buf.h0, L * pl * 8)); CK(hipMalloc(&buf.omega, L * pl * 4)); CK(hipMalloc((void**)&buf.T, L * pl * 32));
     CK(hipMalloc(&buf.disp, L * pl * 8)); CK(hipMalloc(&buf.norm, L * pl * 8)); CK(hipMalloc(&buf.foam, L * pl * 2)); CK(hipMemset(buf.foam, 0, L * pl * 2));
     const int dmode = argc > 3 ? atoi(argv[3]) : 0;  // 0 random O(1), 1 zeros, 2 spectrum-like (tiny away from the centre), 3 tiny but normal (1e-30)
-    std::vector<float> hh(L * pl * 4); for (size_t i = 0; i < hh.size(); ++i) {
+    std::vector<float> hh(L * pl * 2); for (size_t i = 0; i < hh.size(); ++i) {
         float v = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.5f;
-        const size_t tex = (i / 4) % pl; const int x = (int)(tex % N) - N / 2, y = (int)(tex / N) - N / 2;
+        const size_t tex = (i / 2) % pl; const int x = (int)(tex % N) - N / 2, y = (int)(tex / N) - N / 2;
         if (dmode == 1) v = 0.0f;
         if (dmode == 2) v *= (x * x + y * y < 60 * 60) ? 1.0f : 1e-42f;
         if (dmode == 3) v *= (x * x + y * y < 60 * 60) ? 1.0f : 1e-30f;
