@@ -25,7 +25,7 @@ namespace ow {
 // VAR bits (kbench only; the product instantiates VAR = 0):
 //   1 = no global loads (synthetic data), 2 = no stores, 4 = no FFT, 8 = per-wave timestamps
 struct Stamp {
-    unsigned long long t[6];
+    unsigned long long t[16];
     unsigned xcc, pad;
 };
 struct DebugArgs {
@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 #define OW_STAMP(k, keep)                          \
     if constexpr ((VAR & 8) != 0) {                \
         asm volatile("" ::"v"(keep));              \
-        ts[k] = wall_clock64();                    \
+        ts[k] = __builtin_readcyclecounter();      \
     }
 
 // copy the constant twiddle table (global, plan_tw_total(N) entries) into this workgroup's LDS
@@ -126,7 +126,7 @@ template <int W>
 __device__ __forceinline__ void write_stamps(const unsigned long long *ts, const DebugArgs &dbg) {
     if ((threadIdx.x & 63) == 0) {
         Stamp st;
-        for (int k = 0; k < 6; ++k) st.t[k] = ts[k];
+        for (int k = 0; k < 16; ++k) st.t[k] = ts[k];
         st.xcc = xcc_id();
         st.pad = 0;
         dbg.stamps[blockIdx.x * W + threadIdx.x / 64] = st;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
     constexpr bool kLoad = (VAR & 1) == 0;
-    unsigned long long ts[(VAR & 8) ? 6 : 1] = {0};
+    unsigned long long ts[(VAR & 8) ? 16 : 1] = {0};
     OW_STAMP(0, t)
 
     int slot, row0;
@@ -178,6 +178,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     OW_STAMP(1, h[0].x)
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
+    float ik[P];
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
     float keep = 0.0f;
 
 #pragma unroll
@@ -190,21 +192,22 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
             const int to = opaque(t);
 #pragma unroll
             for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
-            if (L == 0) Pass1<N>::template layer_input<0>(d, h, to, kyo, dkxo);
-            if (L == 1) Pass1<N>::template layer_input<1>(d, h, to, kyo, dkxo);
-            if (L == 2) Pass1<N>::template layer_input<2>(d, h, to, kyo, dkxo);
-            if (L == 3) Pass1<N>::template layer_input<3>(d, h, to, kyo, dkxo);
+            if (L == 0) Pass1<N>::template layer_input<0>(d, h, ik, to, kyo, dkxo);
+            if (L == 1) Pass1<N>::template layer_input<1>(d, h, ik, to, kyo, dkxo);
+            if (L == 2) Pass1<N>::template layer_input<2>(d, h, ik, to, kyo, dkxo);
+            if (L == 3) Pass1<N>::template layer_input<3>(d, h, ik, to, kyo, dkxo);
         }
         OW_SCHED_FENCE();
+        OW_STAMP(2 + 3 * L, d[0].x)
         if constexpr (kFft) row_ifft<N>(d, t, lds_row, tw_lds);
-        if (L == 1) { OW_STAMP(2, d[0].x) }
-        if (L == 3) { OW_STAMP(3, d[0].x) }
+        OW_STAMP(3 + 3 * L, d[0].x)
         if (kStore || dbg.never_true) {
             row_sync<N>();  // the row's exchange reads are done before its region becomes the staging image
             Pass1<N>::stage_write(d, t, lds_row);
             lds_barrier();
             Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
             lds_barrier();
+            OW_STAMP(4 + 3 * L, keep)
         } else {
 #pragma unroll
             for (int j = 0; j < P; ++j) keep += d[j].x + d[j].y;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     if (!kStore && keep == 12345.678f) buf.T[t] = cplx{keep, keep};
     if constexpr ((VAR & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[4] = wall_clock64();
+        ts[14] = __builtin_readcyclecounter();
         write_stamps<(plan_wg_threads(N) + 63) / 64>(ts, dbg);
     }
 }
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
     constexpr bool kLoad = (VAR & 1) == 0;
-    unsigned long long ts[(VAR & 8) ? 6 : 1] = {0};
+    unsigned long long ts[(VAR & 8) ? 16 : 1] = {0};
     OW_STAMP(0, t)
 
     int slot, row0;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     if (!kStore && keep == 12345.678f) buf.disp[t] = u16x4{1, 2, 3, 4};
     if constexpr ((VAR & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[4] = wall_clock64();
+        ts[14] = __builtin_readcyclecounter();
         write_stamps<(plan_wg_threads(N) + 63) / 64>(ts, dbg);
     }
 }

@@ -95,19 +95,21 @@ void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, u
     // ---- pass 1 (mirrors k_pass1) ----
     {
         static cplx h[NT][P], d[NT][P];
+        static float ik[NT][P];
         for (int row0 = 0; row0 < N; row0 += kWgRows) {
             for (int l = 0; l < NT; ++l) {
                 const int y = row0 + l / Tn, t = l % Tn;
                 Pass1<N>::load_modulate(h[l], t, y, h0_c, om_c, cf.time);
             }
+            for (int l = 0; l < NT; ++l) Pass1<N>::wave_numbers(ik[l], l % Tn, (float)(row0 + l / Tn - N / 2) * dky, dkx);
             for (int L = 0; L < kLayers; ++L) {
                 for (int l = 0; l < NT; ++l) {
                     const int y = row0 + l / Tn, t = l % Tn;
                     const float ky = (float)(y - N / 2) * dky;
-                    if (L == 0) Pass1<N>::template layer_input<0>(d[l], h[l], t, ky, dkx);
-                    if (L == 1) Pass1<N>::template layer_input<1>(d[l], h[l], t, ky, dkx);
-                    if (L == 2) Pass1<N>::template layer_input<2>(d[l], h[l], t, ky, dkx);
-                    if (L == 3) Pass1<N>::template layer_input<3>(d[l], h[l], t, ky, dkx);
+                    if (L == 0) Pass1<N>::template layer_input<0>(d[l], h[l], ik[l], t, ky, dkx);
+                    if (L == 1) Pass1<N>::template layer_input<1>(d[l], h[l], ik[l], t, ky, dkx);
+                    if (L == 2) Pass1<N>::template layer_input<2>(d[l], h[l], ik[l], t, ky, dkx);
+                    if (L == 3) Pass1<N>::template layer_input<3>(d[l], h[l], ik[l], t, ky, dkx);
                 }
                 w.row_ifft(d);
                 for (int l = 0; l < NT; ++l) Pass1<N>::stage_write(d[l], l % Tn, w.row(l));

@@ -25,8 +25,12 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
 
 
-def fp16_close(a_bits_or_f16, b_bits_or_f16, ulps=1, rel_floor=2e-6):
-    """|a-b| <= ulps * spacing_fp16(|b|) + rel_floor * max|b| per channel (last axis); returns worst ratio."""
+def fp16_close(a_bits_or_f16, b_bits_or_f16, ulps=1, rel_floor=1e-5):
+    """|a-b| <= ulps * spacing_fp16(|b|) + rel_floor * max|b| per channel (last axis); returns worst ratio.
+    One FP16 ulp alone is meaningless near zero crossings (the ulp shrinks with the value while the FP32 error of
+    a 1024-point transform does not), hence the floor relative to the channel maximum: 1e-5, ten times tighter
+    than the 1e-4 FP32 tolerance of north_star.  That the FP16 maps are EXACTLY the round-to-nearest-even
+    quantisation of the FP32 channels is checked separately (quantisation_exact)."""
     a = np.asarray(a_bits_or_f16).view(np.float16)
     b = np.asarray(b_bits_or_f16).view(np.float16)
     af, bf = a.astype(np.float64), b.astype(np.float64)
@@ -34,6 +38,15 @@ def fp16_close(a_bits_or_f16, b_bits_or_f16, ulps=1, rel_floor=2e-6):
     chmax = np.abs(bf).reshape(-1, bf.shape[-1]).max(axis=0)
     allowed = ulps * spacing + rel_floor * chmax
     return float((np.abs(af - bf) / allowed).max())
+
+
+def quantisation_exact(f32, disp_bits, norm_bits):
+    """The RGBA16F maps must be bit for bit the RTE quantisation of the pre-quantisation FP32 channels
+    [hx,hy,hz,gx,gy,dhx_dx,foam,J]: displacement = (hx,hy,hz), normal = (gx,gy,dhx_dx,foam)."""
+    d = np.asarray(disp_bits).view(np.uint16)
+    n = np.asarray(norm_bits).view(np.uint16)
+    q = np.asarray(f32, np.float32).astype(np.float16).view(np.uint16)
+    return bool(np.array_equal(d[..., :3], q[..., 0:3]) and np.array_equal(n[..., :4], q[..., 3:7]))
 
 
 def set_params(cstruct, preset):

@@ -57,6 +57,7 @@ def test_frame_parity_vs_oracle(n, ids):
                 else:
                     assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (frame, i, name)
             disp, norm = gen.get_maps(i)
+            assert H.quantisation_exact(f32, disp, norm)  # the maps ARE the RTE quantisation of the FP32 channels
             assert H.fp16_close(disp, og.displacement(i)) <= 1.0
             assert H.fp16_close(norm[..., :3], og.normal(i)[..., :3]) <= 1.0
             assert np.abs(norm[..., 3].astype(np.float64) - og.normal(i)[..., 3].view(np.float16).astype(np.float64)).max() <= H.TOL_FOAM_ABS

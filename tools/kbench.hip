@@ -94,25 +94,16 @@ int main(int argc, char **argv) {
     // both passes back to back (a tick)
     printf("tick        : %8.2f us\n", time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
                                                       hipLaunchKernelGGL((k_pass2<N, false, 0>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }, iters, s));
-    // timestamps
-    for (int pass = 1; pass <= 2; ++pass) {
-        if (pass == 1) hipLaunchKernelGGL((k_pass1<N, 8>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
-        else hipLaunchKernelGGL((k_pass2<N, false, 8>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg);
+    // timestamps (shader clock cycles, s_memtime), pass 1: per-phase averages over all waves
+    {
+        hipLaunchKernelGGL((k_pass1<N, 8>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg);
         CK(hipStreamSynchronize(s));
-        const int blocks = C * N * plan_T(N) / 64; std::vector<Stamp> h(blocks); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * blocks, hipMemcpyDeviceToHost));
-        unsigned long long tmin = ~0ull; for (auto &x : h) tmin = std::min(tmin, x.t[0]);
-        // wall_clock64 ticks at 100 MHz -> 10 ns
-        double avg[5] = {0}; for (auto &x : h) for (int k = 0; k < 5; ++k) avg[k] += (double)(x.t[k] - tmin) * 0.01 / blocks;
-        printf("pass%d stamps (us, avg over waves): start %.1f  loaded %.1f  half %.1f  fftdone %.1f  stored %.1f\n", pass, avg[0], avg[1], avg[2], avg[3], avg[4]);
-        // distribution of start times and xcc mapping
-        int xccmap[8] = {0}; int agree = 0; for (int b = 0; b < blocks; ++b) { xccmap[h[b].xcc & 7]++; agree += ((int)(h[b].xcc & 7) == b % 8); }
-        printf("  xcc == block%%8 for %d of %d blocks; per-xcc counts:", agree, blocks); for (int i = 0; i < 8; ++i) printf(" %d", xccmap[i]); printf("\n");
-        std::vector<double> starts; for (auto &x : h) starts.push_back((double)(x.t[0] - tmin) * 0.01); std::sort(starts.begin(), starts.end());
-        printf("  start-time percentiles us: p10 %.1f p50 %.1f p90 %.1f max %.1f ; durations: ", starts[blocks / 10], starts[blocks / 2], starts[blocks * 9 / 10], starts.back());
-        std::vector<double> dur; for (auto &x : h) dur.push_back((double)(x.t[4] - x.t[0]) * 0.01); std::sort(dur.begin(), dur.end());
-        printf("p10 %.1f p50 %.1f p90 %.1f\n", dur[blocks / 10], dur[blocks / 2], dur[blocks * 9 / 10]);
-        double seg[4] = {0}; for (auto &x : h) for (int k = 0; k < 4; ++k) seg[k] += (double)(x.t[k + 1] - x.t[k]) * 0.01 / blocks;
-        printf("  avg segment us: load+modulate %.2f | layers01 %.2f | layers23 %.2f | store %.2f\n", seg[0], seg[1], seg[2], seg[3]);
+        const int waves = C * N * plan_T(N) / 64; std::vector<Stamp> h(waves); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));
+        const char *names[15] = {"start", "modulated", "L0 input", "L0 fft", "L0 stored", "L1 input", "L1 fft", "L1 stored", "L2 input", "L2 fft", "L2 stored", "L3 input", "L3 fft", "L3 stored", "drained"};
+        double avg[15] = {0}; unsigned long long tmin = ~0ull; for (auto &x : h) tmin = std::min(tmin, x.t[0]);
+        for (auto &x : h) for (int k = 0; k < 15; ++k) avg[k] += (double)(x.t[k] - tmin) / waves;
+        printf("pass1 phase stamps (kcycles since first wave start; delta):\n");
+        for (int k = 0; k < 15; ++k) printf("  %-10s %8.2f  (+%.2f)\n", names[k], avg[k] / 1e3, k ? (avg[k] - avg[k - 1]) / 1e3 : 0.0);
     }
     return 0;
 }
