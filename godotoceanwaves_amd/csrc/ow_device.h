@@ -675,8 +675,13 @@ struct Pass1 {
     // d[j] = packed layer L at texel x (spectrum_modulate.glsl:72-89); each layer is h times a complex
     // coefficient of the wave vector (u = k / |k|):  L0 = i(1+uy) h, L1 = (-ky + i ux) h, L2 = i(kx - ky uy) h,
     // L3 = -ux (kx + i ky) h; written as  c*h + e*(i h)  so that each is two or three packed instructions.
-    template <int L>
-    static OW_DEV void layer_input(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx) {
+    struct NoHook {
+        OW_DEV void operator()(int) const {}
+    };
+    // after_group(g) is called after texel group g = 0..3 (the pass-1 kernel drains the previous layer's staged
+    // rows there, a few stores at a time, instead of in one burst)
+    template <int L, class Hook = NoHook>
+    static OW_DEV void layer_input(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx, Hook after_group = Hook()) {
         const float kx0 = (float)(t - N / 2) * dkx;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
@@ -692,7 +697,11 @@ struct Pass1 {
                 d[j] = cadd(cscale(h[j], mux * kx), cscale(ih, mux * ky));
             }
             opaque_inplace(d[j]);  // pins this texel's arithmetic here (pure ops would otherwise sink to their first use)
-            if (j % 4 == 3) OW_SCHED_FENCE();  // four texels' temporaries at a time, not sixteen
+            if (j % 4 == 3) {
+                OW_SCHED_FENCE();  // four texels' temporaries at a time, not sixteen
+                after_group(j / 4);
+                OW_SCHED_FENCE();
+            }
         }
     }
 
@@ -715,6 +724,18 @@ struct Pass1 {
         for (int k = 0; k < P; ++k) v[k] = lds_read(st + xi + T * k);
 #pragma unroll
         for (int k = 0; k < P; ++k) gstore8<AUX>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * k, 0)) * 8u, v[k]);
+    }
+    // the same, quarter g = 0..3 of the x' range only (k = 4g .. 4g+3)
+    template <int AUX>
+    static OW_DEV void stage_store_chunk(int tau, int layer, int row0, const cplx *lds_block, GBuf T_c, int g) {
+        const int q = tau % kWgRows, xi = tau / kWgRows;
+        const cplx *st = lds_block + q * plan_region_cplx(N);
+        const uint32_t voff = t_unit(N, 0, xi, row0 + q) * 8u;
+        cplx v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lds_read(st + xi + T * (4 * g + k));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gstore8<AUX>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * (4 * g + k), 0)) * 8u, v[k]);
     }
 };
 

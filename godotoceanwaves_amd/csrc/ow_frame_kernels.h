@@ -71,9 +71,12 @@ __device__ __forceinline__ void load_twiddles(cplx *tw_lds, const cplx *__restri
 }
 
 // row IFFT of the 16 points in d[] (lane t of the row), exchanging through this row's LDS buffer
-template <int N>
+// (BLOCK_GATE: a workgroup barrier right before the first write into the row regions -- pass 1 uses it when
+// other waves may still be draining the previous layer's staged rows out of them)
+template <int N, bool BLOCK_GATE = false>
 __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw) {
     fft_stage_compute<N, 0>(d, t, tw);
+    if constexpr (BLOCK_GATE) lds_barrier();
     fft_stage_write<N, 0>(d, t, lds_row);
     row_sync<N>();
     fft_stage_read<N, 1>(d, t, lds_row);
@@ -182,6 +185,11 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     Pass1<N>::wave_numbers(ik, t, ky, dkx);
     float keep = 0.0f;
 
+    // Layer L's transposed rows are staged in LDS at the end of its transform and written out DURING layer L+1:
+    // a quarter after each texel group of the next layer's input construction (the row regions are not touched
+    // again before the next transform's first exchange, which waits behind a block barrier).  The stores of a
+    // layer thus trickle out under VALU work instead of stalling all waves of the chip in one burst.
+    constexpr bool kDefer = kStore;
 #pragma unroll
     for (int L = 0; L < kLayers; ++L) {
         cplx d[P];
@@ -192,21 +200,28 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
             const int to = opaque(t);
 #pragma unroll
             for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
-            if (L == 0) Pass1<N>::template layer_input<0>(d, h, ik, to, kyo, dkxo);
-            if (L == 1) Pass1<N>::template layer_input<1>(d, h, ik, to, kyo, dkxo);
-            if (L == 2) Pass1<N>::template layer_input<2>(d, h, ik, to, kyo, dkxo);
-            if (L == 3) Pass1<N>::template layer_input<3>(d, h, ik, to, kyo, dkxo);
+            auto drain = [&](int g) {
+                if (kDefer && L > 0) Pass1<N>::template stage_store_chunk<AUX_T>(tau, L - 1, row0, rows_lds, T_c, g);
+            };
+            if (L == 0) Pass1<N>::template layer_input<0>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 1) Pass1<N>::template layer_input<1>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 2) Pass1<N>::template layer_input<2>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 3) Pass1<N>::template layer_input<3>(d, h, ik, to, kyo, dkxo, drain);
         }
         OW_SCHED_FENCE();
         OW_STAMP(2 + 3 * L, d[0].x)
-        if constexpr (kFft) row_ifft<N>(d, t, lds_row, tw_lds);
+        if constexpr (kFft) {
+            if (kDefer && L > 0) row_ifft<N, true>(d, t, lds_row, tw_lds);
+            else row_ifft<N, false>(d, t, lds_row, tw_lds);
+        } else if (kDefer && L > 0) {
+            lds_barrier();
+        }
         OW_STAMP(3 + 3 * L, d[0].x)
         if (kStore || dbg.never_true) {
             row_sync<N>();  // the row's exchange reads are done before its region becomes the staging image
             Pass1<N>::stage_write(d, t, lds_row);
             lds_barrier();
-            Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
-            lds_barrier();
+            if (L == kLayers - 1) Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);  // nothing left to hide under
             OW_STAMP(4 + 3 * L, keep)
         } else {
 #pragma unroll
