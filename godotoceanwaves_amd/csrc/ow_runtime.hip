@@ -9,6 +9,7 @@
 // The reference issues six dispatches per cascade; here a batch of cascades is two launches.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -61,6 +62,10 @@ struct ow_context {
     size_t ev_used = 0;
     double t1_ms = 0, t2_ms = 0;
     int t_launches = 0;
+    float ev_overhead_ms = 0;  // what an event pair around an EMPTY kernel measures (subtracted from every interval)
+    // last batch that was launched (for ow_probe_kernel_times)
+    ow::FrameArgs last_args{};
+    int last_count = 0;
 };
 
 namespace {
@@ -76,8 +81,8 @@ ow_status collect_timing(ow_context *c) {
         float a = 0, b = 0;
         OW_HIP(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
         OW_HIP(hipEventElapsedTime(&b, c->ev[i + 1], c->ev[i + 2]));
-        c->t1_ms += a;
-        c->t2_ms += b;
+        c->t1_ms += a > c->ev_overhead_ms ? a - c->ev_overhead_ms : 0.0f;
+        c->t2_ms += b > c->ev_overhead_ms ? b - c->ev_overhead_ms : 0.0f;
         c->t_launches += 1;
     }
     c->ev_used = 0;
@@ -135,16 +140,29 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
         cf.cascade = idx[i];
     }
-    hipEvent_t *ev = nullptr;
-    if (c->timing) {
-        ow_status st = next_events(c, &ev);
-        if (st != OW_OK) return st;
-        OW_HIP(hipEventRecord(ev[0], c->stream));
+    // Launch in batches whose transposed intermediate (32 B/texel) stays inside the 256 MiB Infinity Cache between
+    // pass 1 and pass 2: at most 4 Mi texels (= 1024^2 x 4 = 128 MiB of T) per pair of launches.  Larger batches
+    // would stream T through HBM twice; smaller ones only add launches.  Cascades are independent, so batching does
+    // not change any result.
+    const int per_batch = std::max(1, (int)((4u << 20) / ((size_t)c->n * c->n)));
+    for (int b0 = 0; b0 < count; b0 += per_batch) {
+        const int nb = std::min(per_batch, count - b0);
+        ow::FrameArgs part;
+        std::memset(&part, 0, sizeof(part));
+        for (int i = 0; i < nb; ++i) part.c[i] = args.c[b0 + i];
+        c->last_args = part;
+        c->last_count = nb;
+        hipEvent_t *ev = nullptr;
+        if (c->timing) {
+            ow_status st = next_events(c, &ev);
+            if (st != OW_OK) return st;
+            OW_HIP(hipEventRecord(ev[0], c->stream));
+        }
+        OW_HIP(ow::launch_pass1(c->n, nb, part, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
+        if (ev) OW_HIP(hipEventRecord(ev[1], c->stream));
+        OW_HIP(ow::launch_pass2(c->n, nb, part, c->buf, c->stream));  // rows + unpack (:82-85)
+        if (ev) OW_HIP(hipEventRecord(ev[2], c->stream));
     }
-    OW_HIP(ow::launch_pass1(c->n, count, args, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
-    if (ev) OW_HIP(hipEventRecord(ev[1], c->stream));
-    OW_HIP(ow::launch_pass2(c->n, count, args, c->buf, c->stream));  // rows + unpack (:82-85)
-    if (ev) OW_HIP(hipEventRecord(ev[2], c->stream));
     return OW_OK;
 }
 
@@ -441,15 +459,60 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     return OW_OK;
 }
 
+ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float *p2_ms, int32_t *cascades_per_launch) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (reps < 1 || c->last_count < 1) return fail(OW_ERR_STATE, "nothing has been launched yet (or reps < 1)");
+    OW_HIP(hipSetDevice(c->device));
+    hipEvent_t e[3];
+    for (auto &x : e) OW_HIP(hipEventCreate(&x));
+    OW_HIP(hipEventRecord(e[0], c->stream));
+    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->last_args, c->buf, c->stream));
+    OW_HIP(hipEventRecord(e[1], c->stream));
+    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->last_args, c->buf, c->stream));
+    OW_HIP(hipEventRecord(e[2], c->stream));
+    OW_HIP(hipEventSynchronize(e[2]));
+    float a = 0, b = 0;
+    OW_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+    OW_HIP(hipEventElapsedTime(&b, e[1], e[2]));
+    for (auto &x : e) (void)hipEventDestroy(x);
+    if (p1_ms) *p1_ms = a / reps;
+    if (p2_ms) *p2_ms = b / reps;
+    if (cascades_per_launch) *cascades_per_launch = c->last_count;
+    return OW_OK;
+}
+
 ow_status ow_timing_enable(ow_context *c, int32_t enable) {
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (!enable) {
         ow_status st = collect_timing(c);
         if (st != OW_OK) return st;
     }
+    if (enable && !c->timing) {
+        // calibrate: an event pair around an empty kernel measures marker processing + dispatch latency, which a
+        // rocprofv3 kernel trace does not count as kernel time; the minimum of a few tries is subtracted later
+        OW_HIP(hipSetDevice(c->device));
+        hipEvent_t e0, e1;
+        OW_HIP(hipEventCreate(&e0));
+        OW_HIP(hipEventCreate(&e1));
+        float best = 1e9f;
+        for (int i = 0; i < 8; ++i) {
+            OW_HIP(hipEventRecord(e0, c->stream));
+            OW_HIP(ow::launch_empty(c->stream));
+            OW_HIP(hipEventRecord(e1, c->stream));
+            OW_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            OW_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (i > 1 && ms < best) best = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        c->ev_overhead_ms = best < 1e8f ? best : 0.0f;
+    }
     c->timing = enable != 0;
     return OW_OK;
 }
+
+float ow_timing_overhead_ms(const ow_context *c) { return c ? c->ev_overhead_ms : 0.0f; }
 
 ow_status ow_timing_read(ow_context *c, float *p1, float *p2, int32_t *launches, int32_t reset) {
     if (!c) return fail(OW_ERR_INVALID, "null context");

@@ -228,6 +228,16 @@ class WaveGenerator:
     def timing(self, enable):
         _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
 
+    def timing_overhead_ms(self):
+        return float(self._lib.ow_timing_overhead_ms(self.context))
+
+    def probe_kernel_times(self, reps=50):
+        """(pass1_ms, pass2_ms, cascades_per_launch): each kernel alone, `reps` back-to-back launches (benchmark probe;
+        the extra pass-2 launches advance the foam state)"""
+        a, b, n = C.c_float(), C.c_float(), C.c_int32()
+        _lib.check(self._lib.ow_probe_kernel_times(self.context, reps, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def timing_read(self, reset=True):
         a, b, n = C.c_float(), C.c_float(), C.c_int32()
         _lib.check(self._lib.ow_timing_read(self.context, C.byref(a), C.byref(b), C.byref(n), 1 if reset else 0))

@@ -162,6 +162,16 @@ double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_
  * per launch, so throughput runs keep it off. */
 ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
+/* What an event pair around an EMPTY kernel measures on this stream (marker processing + dispatch latency);
+ * calibrated by ow_timing_enable and already subtracted from the averages of ow_timing_read. */
+float ow_timing_overhead_ms(const ow_context *ctx);
+
+/* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
+ * and then `reps` of pass 2 with the arguments of the most recent batch, bracketed by hipEvents on the context's
+ * stream (one pair of events per block of launches, so the event cost is amortised and the figure agrees with a
+ * rocprofv3 kernel trace).  The extra pass-2 launches advance the foam recurrence: call it after a measurement,
+ * never inside a simulation.  cascades_per_launch = how many cascades one launch of that batch covered. */
+ow_status ow_probe_kernel_times(ow_context *ctx, int32_t reps, float *pass1_ms, float *pass2_ms, int32_t *cascades_per_launch);
 
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char *ow_last_error(void);
