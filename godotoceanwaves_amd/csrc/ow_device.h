@@ -844,6 +844,37 @@ struct Pass2 {
             }
         }
     }
+    // The whole of fft_unpack.glsl:44-67 for ONE texel whose four layer values are at hand (layer-parallel pass 2).
+    // foam_prev / foam_new: FP16 bits of the recurrent state.  o = the lane's output ordinal (texel t + T*o).
+    template <bool F32, int AUX>
+    static OW_DEV uint16_t unpack_texel(cplx l0, cplx l1, cplx l2, cplx l3, uint16_t foam_prev, int t, int xp, int o, uint32_t tex,
+                                        const CascadeFrame &cf, GBuf disp_c, GBuf norm_c, GBuf f32_c) {
+        const float dhy_dz = l2.x, dhx_dx = l2.y, dhz_dz = l3.x, dhz_dx = l3.y;
+        const float jac = (1.0f + dhx_dx) * (1.0f + dhz_dz) - dhz_dx * dhz_dx;
+        const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
+        float foam = h2f(foam_prev);
+        foam = mul_rn(foam, cf.foam_decay);
+        foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
+        foam = fminf(fmaxf(foam, 0.0f), 1.0f);
+        const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
+        const float gx = l1.y * fast_rcp(1.0f + fabsf(dhx_dx));
+        const uint16_t foam_h = f2h(foam);
+        const uint16_t w = (uint16_t)(((xp ^ t) & 1) << 15);
+        gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(gx), f2h(gy), f2h(dhx_dx), foam_h});
+        gstore8h<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(l0.x), f2h(l0.y), f2h(l1.x), w});
+        if (F32) {
+            f32_put(f32_c, tex, o, 0, l0.x);
+            f32_put(f32_c, tex, o, 1, l0.y);
+            f32_put(f32_c, tex, o, 2, l1.x);
+            f32_put(f32_c, tex, o, 3, gx);
+            f32_put(f32_c, tex, o, 4, gy);
+            f32_put(f32_c, tex, o, 5, dhx_dx);
+            f32_put(f32_c, tex, o, 6, foam);
+            f32_put(f32_c, tex, o, 7, jac);
+        }
+        return foam_h;
+    }
+
     // layer 0 done (fft_unpack.glsl:44-50): displacement = (hx, hy, hz, 0) * sign; the sign only survives in the
     // zero of .w (0 * -1 = -0): sign bit = parity of x' + y', and y' = t + T*o has the parity of t
     template <bool F32, int AUX>

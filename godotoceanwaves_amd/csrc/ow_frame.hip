@@ -5,14 +5,32 @@ namespace ow {
 
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
+// Small batches take the layer-parallel kernels: below ~2048 waves of row work the standard kernels cannot fill
+// the chip and run at one wave's serial latency.  mode: 0 = choose by size, 1 = standard, 2 = layer-parallel.
 template <int N>
-static hipError_t launch1(int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+static bool use_lp(int slots, int mode) {
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    return (long)slots * N * plan_T(N) / 64 <= 2048;
+}
+template <int N>
+static hipError_t launch1(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
     const int blocks = slots * (N / kWgRows);
+    if (use_lp<N>(slots, mode)) {
+        hipLaunchKernelGGL((k_pass1_lp<N>), dim3(blocks, kLayers), dim3(plan_wg_threads(N)), 0, s, buf, args);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_pass1<N>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 template <int N>
-static hipError_t launch2(int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+static hipError_t launch2(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+    if (use_lp<N>(slots, mode)) {
+        const int lp_blocks = slots * (N / plan_lp_rows(N));
+        if (buf.f32) hipLaunchKernelGGL((k_pass2_lp<N, true>), dim3(lp_blocks), dim3(plan_lp_threads(N)), 0, s, buf, args);
+        else hipLaunchKernelGGL((k_pass2_lp<N, false>), dim3(lp_blocks), dim3(plan_lp_threads(N)), 0, s, buf, args);
+        return hipGetLastError();
+    }
     const int blocks = slots * (N / kWgRows);
     if (buf.f32) hipLaunchKernelGGL((k_pass2<N, true>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
     else hipLaunchKernelGGL((k_pass2<N, false>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
@@ -25,23 +43,23 @@ hipError_t launch_empty(hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_pass1(int n, int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
     switch (n) {
-        case 128: return launch1<128>(slots, args, buf, s);
-        case 256: return launch1<256>(slots, args, buf, s);
-        case 512: return launch1<512>(slots, args, buf, s);
-        case 1024: return launch1<1024>(slots, args, buf, s);
-        case 2048: return launch1<2048>(slots, args, buf, s);
+        case 128: return launch1<128>(slots, mode, args, buf, s);
+        case 256: return launch1<256>(slots, mode, args, buf, s);
+        case 512: return launch1<512>(slots, mode, args, buf, s);
+        case 1024: return launch1<1024>(slots, mode, args, buf, s);
+        case 2048: return launch1<2048>(slots, mode, args, buf, s);
     }
     return hipErrorInvalidValue;
 }
-hipError_t launch_pass2(int n, int slots, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
     switch (n) {
-        case 128: return launch2<128>(slots, args, buf, s);
-        case 256: return launch2<256>(slots, args, buf, s);
-        case 512: return launch2<512>(slots, args, buf, s);
-        case 1024: return launch2<1024>(slots, args, buf, s);
-        case 2048: return launch2<2048>(slots, args, buf, s);
+        case 128: return launch2<128>(slots, mode, args, buf, s);
+        case 256: return launch2<256>(slots, mode, args, buf, s);
+        case 512: return launch2<512>(slots, mode, args, buf, s);
+        case 1024: return launch2<1024>(slots, mode, args, buf, s);
+        case 2048: return launch2<2048>(slots, mode, args, buf, s);
     }
     return hipErrorInvalidValue;
 }

@@ -336,4 +336,113 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     }
 }
 
+
+// ===================================================================================================
+// LAYER-PARALLEL variants for small batches (fewer than ~2048 waves of work: one cascade of 1024^2, anything at
+// 128^2 .. 512^2).  There the standard kernels leave most of the chip idle and their duration is one wave's serial
+// latency (four transforms back to back).  Here every (row, layer) pair gets its own lanes: 4x the waves, a quarter
+// of the serial work each.  Same lane code, same results up to FMA contraction order.
+// ===================================================================================================
+
+// PASS 1, layer-parallel: grid (rows/8, 4); block y = the packed layer this block transforms.  Each of the four blocks
+// of a row group loads and modulates the spectrum itself (the duplicates are L2 hits; the chip is idle anyway).
+template <int N, int AUX_T = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    const int L = blockIdx.y;
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    const int y = row0 + rw;
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    cplx h[P];
+    Pass1<N>::load_modulate(h, t, y, h0_c, om_c, cf.time);
+    load_twiddles<N>(tw_lds, buf.tw);
+    const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    const float ky = (float)(y - N / 2) * dky;
+    float ik[P];
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    cplx d[P];
+    OW_SCHED_FENCE();
+    switch (L) {  // block-uniform
+        case 0: Pass1<N>::template layer_input<0>(d, h, ik, t, ky, dkx); break;
+        case 1: Pass1<N>::template layer_input<1>(d, h, ik, t, ky, dkx); break;
+        case 2: Pass1<N>::template layer_input<2>(d, h, ik, t, ky, dkx); break;
+        default: Pass1<N>::template layer_input<3>(d, h, ik, t, ky, dkx); break;
+    }
+    OW_SCHED_FENCE();
+    row_ifft<N>(d, t, lds_row, tw_lds);
+    row_sync<N>();
+    Pass1<N>::stage_write(d, t, lds_row);
+    lds_barrier();
+    Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+}
+
+// PASS 2, layer-parallel: a block = plan_lp_rows(N) rows x 4 layers x N/16 lanes (512 threads).  Every (row, layer)
+// lane group transforms its layer, leaves it in its LDS region in natural order, and after one block barrier each
+// layer group finishes a quarter of the row's texels (fft_unpack.glsl for texels o = 4g .. 4g+3 of every lane).
+constexpr int plan_lp_rows(int N) { return 128 / plan_T(N) > 0 ? 128 / plan_T(N) : 1; }
+constexpr int plan_lp_threads(int N) { return plan_lp_rows(N) * kLayers * plan_T(N); }
+constexpr int plan_lp_lds_cplx(int N) { return plan_region_cplx(N) * plan_lp_rows(N) * kLayers + plan_tw_total(N); }
+
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
+__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);  // layer of this lane group (wave-uniform: PER_LAYER >= 128)
+    const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    constexpr int BPC = N / ROWS;
+    const int slot = blockIdx.x / BPC, row0 = (blockIdx.x % BPC) * ROWS;
+    const CascadeFrame cf = args.c[slot];
+    const int xp = row0 + r;
+    const uint32_t tex = (uint32_t)(xp * N + t);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
+    const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
+    auto region = [&](int row, int layer) { return rows_lds + (layer * ROWS + row) * plan_region_cplx(N); };
+
+    cplx d[P];
+    Pass2<N>::template load_layer<AUX_T>(d, t, xp, g, T_c);
+    // this group's quarter of the lane's foam values (o = 4g .. 4g+3): 8 bytes of the lane's 32
+    const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
+    load_twiddles<N>(tw_lds, buf.tw);
+    row_ifft<N>(d, t, region(r, g), tw_lds);
+    row_sync<N>();
+    {
+        cplx *mine = region(r, g);
+#pragma unroll
+        for (int o = 0; o < P; ++o) mine[t + Tn * o] = d[OutMap<N>::slot_of(o)];
+    }
+    lds_barrier();
+    const float fb0 = foam_bits.x, fb1 = foam_bits.y;
+    const uint32_t fpk[2] = {__builtin_bit_cast(uint32_t, fb0), __builtin_bit_cast(uint32_t, fb1)};
+    uint32_t fnew[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = 4 * g + q;  // group-uniform
+        const int e = t + Tn * o;
+        const cplx l0 = lds_read(region(r, 0) + e), l1 = lds_read(region(r, 1) + e), l2 = lds_read(region(r, 2) + e), l3 = lds_read(region(r, 3) + e);
+        const uint16_t prev = (uint16_t)((fpk[q / 2] >> (16 * (q & 1))) & 0xFFFFu);
+        const uint32_t fh = Pass2<N>::template unpack_texel<F32, AUX_O>(l0, l1, l2, l3, prev, t, xp, o, tex, cf, disp_c, norm_c, f32_c);
+        fnew[q / 2] |= fh << (16 * (q & 1));
+    }
+    const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
+    gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
+}
+
 }  // namespace ow

@@ -49,6 +49,7 @@ constexpr double kHostG = 9.81;  // wave_generator.gd:5
 struct ow_context {
     int n = 0, cascades = 0, layers = 0, device = 0;
     float depth = 20.0f;
+    int kernel_mode = 0;  // 0 = by batch size, 1 = standard kernels, 2 = layer-parallel kernels (OW_FLAG_KERNELS_*)
     hipStream_t stream = nullptr;
     bool own_stream = false, own_disp = false, own_norm = false;
     ow::DeviceBuffers buf{};
@@ -158,9 +159,9 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
             if (st != OW_OK) return st;
             OW_HIP(hipEventRecord(ev[0], c->stream));
         }
-        OW_HIP(ow::launch_pass1(c->n, nb, part, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
+        OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
         if (ev) OW_HIP(hipEventRecord(ev[1], c->stream));
-        OW_HIP(ow::launch_pass2(c->n, nb, part, c->buf, c->stream));  // rows + unpack (:82-85)
+        OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, c->stream));  // rows + unpack (:82-85)
         if (ev) OW_HIP(hipEventRecord(ev[2], c->stream));
     }
     return OW_OK;
@@ -230,6 +231,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->layers = cfg->num_cascades < 2 ? 2 : cfg->num_cascades;  // init_gpu(maxi(2, n)), water.gd:91
     c->device = dev;
     c->depth = cfg->depth > 0.0f ? cfg->depth : 20.0f;  // DEPTH, wave_generator.gd:6
+    c->kernel_mode = (cfg->flags & OW_FLAG_KERNELS_STANDARD) ? 1 : ((cfg->flags & OW_FLAG_KERNELS_LAYER_PARALLEL) ? 2 : 0);
 
     auto bail = [&](ow_status st) {
         ow_destroy(c);
@@ -466,9 +468,9 @@ ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float
     hipEvent_t e[3];
     for (auto &x : e) OW_HIP(hipEventCreate(&x));
     OW_HIP(hipEventRecord(e[0], c->stream));
-    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->last_args, c->buf, c->stream));
+    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
     OW_HIP(hipEventRecord(e[1], c->stream));
-    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->last_args, c->buf, c->stream));
+    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
     OW_HIP(hipEventRecord(e[2], c->stream));
     OW_HIP(hipEventSynchronize(e[2]));
     float a = 0, b = 0;

@@ -11,7 +11,8 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import OW_FLAG_DEBUG_F32, ow_cascade_params, ow_config
+from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, ow_cascade_params,
+                   ow_config)
 
 G = 9.81       # wave_generator.gd:5
 DEPTH = 20.0   # wave_generator.gd:6
@@ -105,6 +106,7 @@ class WaveGenerator:
         self._lib = None
         self.depth = DEPTH
         self.debug_f32 = False
+        self.kernels = None           # None = runtime picks per batch; "standard" / "layer_parallel" pin the kernel family
         self.device_id = -1
         self.stream = None
         self.external_maps = (None, None)  # optional caller-owned device buffers (displacement, normal)
@@ -121,7 +123,8 @@ class WaveGenerator:
             self.free()
         cfg = ow_config(map_size=int(self.map_size), num_cascades=int(num_cascades), device_id=self.device_id,
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
-                        normal_map=self.external_maps[1], flags=OW_FLAG_DEBUG_F32 if self.debug_f32 else 0)
+                        normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) |
+                        {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL}[self.kernels])
         ctx = C.c_void_p()
         _lib.check(self._lib.ow_create(C.byref(cfg), C.byref(ctx)))
         self.context = ctx

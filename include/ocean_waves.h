@@ -74,6 +74,11 @@ typedef struct ow_config {
 } ow_config;
 
 #define OW_FLAG_DEBUG_F32 1u /* also keep 8 pre-quantisation FP32 channels per texel (parity tests) */
+/* Kernel family.  By default the runtime picks per batch: the layer-parallel kernels (one lane group per row AND
+ * packed layer) when a batch is too small to fill the chip, the standard ones (one lane group per row, layers in
+ * sequence) otherwise.  These two flags pin the choice (tests, measurements). */
+#define OW_FLAG_KERNELS_STANDARD 2u
+#define OW_FLAG_KERNELS_LAYER_PARALLEL 4u
 
 typedef struct ow_context ow_context;
 

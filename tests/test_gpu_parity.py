@@ -11,10 +11,11 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def make_gen(n, cascade_ids, debug=True):
+def make_gen(n, cascade_ids, debug=True, kernels=None):
     gen = WaveGenerator()
     gen.map_size = n
     gen.debug_f32 = debug
+    gen.kernels = kernels
     gen.init_gpu(max(2, len(cascade_ids)))
     params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in cascade_ids]
     return gen, params
@@ -38,11 +39,12 @@ def test_spectrum_and_omega(n):
         assert mism <= 2, f"{mism} omega texels differ"  # P(double-rounding disagreement) ~ 2^-28 per texel
 
 
+@pytest.mark.parametrize("kernels", ["standard", "layer_parallel"])
 @pytest.mark.parametrize("n,ids", [(128, [0]), (256, [0, 1, 2, 3]), (512, [2, 4]), (1024, [2])])
-def test_frame_parity_vs_oracle(n, ids):
+def test_frame_parity_vs_oracle(n, ids, kernels):
     """3 frames of modulate + IFFT + unpack: FP32 channels <= 1e-4 max-norm relative, FP16 maps <= 1 ulp,
     intermediate (after the first row pass + transpose) <= 1e-5."""
-    gen, params = make_gen(n, ids)
+    gen, params = make_gen(n, ids, kernels=kernels)
     og = H.oracle_generator(n, ids)
     for frame in range(3):
         gen.update_all(UPDATE_DELTA, params)
