@@ -5,13 +5,13 @@ namespace ow {
 
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
-// Small batches take the layer-parallel kernels: below ~2048 waves of row work the standard kernels cannot fill
+// Small batches take the layer-parallel kernels: up to ~1024 waves of row work the standard kernels cannot fill
 // the chip and run at one wave's serial latency.  mode: 0 = choose by size, 1 = standard, 2 = layer-parallel.
 template <int N>
 static bool use_lp(int slots, int mode) {
     if (mode == 1) return false;
     if (mode == 2) return true;
-    return (long)slots * N * plan_T(N) / 64 <= 2048;
+    return (long)slots * N * plan_T(N) / 64 <= 1024;  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
 }
 template <int N>
 static hipError_t launch1(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {

@@ -338,8 +338,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 
 
 // ===================================================================================================
-// LAYER-PARALLEL variants for small batches (fewer than ~2048 waves of work: one cascade of 1024^2, anything at
-// 128^2 .. 512^2).  There the standard kernels leave most of the chip idle and their duration is one wave's serial
+// LAYER-PARALLEL variants for small batches (up to ~1024 waves of row work: one cascade of 1024^2, four of 512^2, anything at
+// 128^2 and 256^2).  There the standard kernels leave most of the chip idle and their duration is one wave's serial
 // latency (four transforms back to back).  Here every (row, layer) pair gets its own lanes: 4x the waves, a quarter
 // of the serial work each.  Same lane code, same results up to FMA contraction order.
 // ===================================================================================================
