@@ -168,7 +168,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
 
     cplx h[P];
     if constexpr (kLoad) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     const CascadeFrame cf = args.c[slot];
     const int xp = row0 + rw;
     const uint32_t tex = (uint32_t)(xp * N + t);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
     const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
     cplx h[P];
     Pass1<N>::load_modulate(h, t, y, h0_c, om_c, cf.time);
     load_twiddles<N>(tw_lds, buf.tw);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     const CascadeFrame cf = args.c[slot];
     const int xp = row0 + r;
     const uint32_t tex = (uint32_t)(xp * N + t);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)cf.cascade * plane * kLayers, t_cascade_bytes(N));
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
     const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);

@@ -10,7 +10,8 @@ struct DeviceBuffers {
     cplx *h0;       // [layers][N][N] complex h0(k): first half of the `spectrum` texel (wave_generator.gd:31); the second half,
                     // conj(h0(-k)), is the mirrored texel of the same plane (Pass1::load_modulate)
     float *omega;   // [layers][N][N]          FP32 dispersion plane
-    cplx *T;        // [layers][4 packed layers][N/16 y/16][N x'][16 y%16] complex: transposed intermediate
+    cplx *T;        // [launch slot][4 packed layers][N/16 y/16][N x'][16 y%16] complex: transposed intermediate (scratch between the
+                    // two passes of ONE batch: indexed by the slot inside the launch, not by cascade, so every batch reuses it)
     u16x4 *disp;    // [layers][N][N] RGBA16F
     u16x4 *norm;    // [layers][N][N] RGBA16F (foam in .a)
     uint16_t *foam; // [layers][N x'][N/16 t][16 o] FP16: private copy of normal.a in pass-2 lane order (Pass2::foam_index)

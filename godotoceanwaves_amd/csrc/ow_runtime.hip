@@ -64,6 +64,7 @@ struct ow_context {
     double t1_ms = 0, t2_ms = 0;
     int t_launches = 0;
     float ev_overhead_ms = 0;  // what an event pair around an EMPTY kernel measures (subtracted from every interval)
+    int slot_of[OW_MAX_CASCADES];  // launch slot of each cascade in the most recent batch, -1 if it was not in it
     // last batch that was launched (for ow_probe_kernel_times)
     ow::FrameArgs last_args{};
     int last_count = 0;
@@ -72,6 +73,10 @@ struct ow_context {
 namespace {
 
 size_t plane(const ow_context *c) { return (size_t)c->n * c->n; }
+
+// cascades per pair of launches: at most 4 Mi texels, so that the 32 B/texel intermediate (<= 128 MiB) is still in the
+// 256 MiB Infinity Cache when pass 2 reads it
+int batch_size(const ow_context *c) { return std::max(1, (int)((4u << 20) / ((size_t)c->n * c->n))); }
 
 constexpr size_t kMaxTimedBatches = 4096;
 
@@ -145,7 +150,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
     // pass 1 and pass 2: at most 4 Mi texels (= 1024^2 x 4 = 128 MiB of T) per pair of launches.  Larger batches
     // would stream T through HBM twice; smaller ones only add launches.  Cascades are independent, so batching does
     // not change any result.
-    const int per_batch = std::max(1, (int)((4u << 20) / ((size_t)c->n * c->n)));
+    const int per_batch = batch_size(c);
     for (int b0 = 0; b0 < count; b0 += per_batch) {
         const int nb = std::min(per_batch, count - b0);
         ow::FrameArgs part;
@@ -153,6 +158,8 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         for (int i = 0; i < nb; ++i) part.c[i] = args.c[b0 + i];
         c->last_args = part;
         c->last_count = nb;
+        for (int &sl : c->slot_of) sl = -1;
+        for (int i = 0; i < nb; ++i) c->slot_of[part.c[i].cascade] = i;
         hipEvent_t *ev = nullptr;
         if (c->timing) {
             ow_status st = next_events(c, &ev);
@@ -250,7 +257,9 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         return bail(fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #ptr, (size_t)(bytes)));
     OW_ALLOC(c->buf.h0, L * pl * sizeof(ow::cplx));                   // h0(k): the non-redundant half of the spectrum texture (:31)
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
-    OW_ALLOC(c->buf.T, L * pl * ow::kLayers * sizeof(ow::cplx));  // half of the reference's fft_buffer (:33)
+    // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
+    // is the same <= 128 MiB for every batch and stays in the Infinity Cache
+    OW_ALLOC(c->buf.T, (size_t)std::min((int)L, batch_size(c)) * pl * ow::kLayers * sizeof(ow::cplx));
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -279,6 +288,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "initial upload failed: %s", hipGetErrorString(hipGetLastError())));
+    for (int &sl : c->slot_of) sl = -1;
     *out = c;
     return OW_OK;
 }
@@ -444,7 +454,9 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     OW_HIP(hipSetDevice(c->device));
     const size_t pl = plane(c), n = (size_t)c->n;
     std::vector<ow::cplx> t(pl * ow::kLayers);
-    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + cascade * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
+    if (c->slot_of[cascade] < 0)
+        return fail(OW_ERR_STATE, "cascade %d was not part of the most recent batch: its intermediate has been overwritten", cascade);
+    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + (size_t)c->slot_of[cascade] * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
     // device layout T[layer][y/16][x'][y%16]  ->  reference half-0-after-transpose layout [layer][row = x'][col = y].
     // The device rows carry the x' half of the ifftshift sign, (-1)^x' (see Pass1::rot): taken out again here.

@@ -153,7 +153,8 @@ ow_status ow_get_maps_f32(ow_context *ctx, int32_t cascade, float *out);
 ow_status ow_get_spectrum(ow_context *ctx, int32_t cascade, float *h0, float *omega);
 
 /* The transposed intermediate after the first row pass, converted to the reference's layout
- * fft_buffer half 0 after transpose.glsl: [layer][row][col] complex, 4*N*N*2 floats. */
+ * fft_buffer half 0 after transpose.glsl: [layer][row][col] complex, 4*N*N*2 floats.  The intermediate is scratch
+ * shared by all batches: only cascades of the most recent pair of launches can be read (OW_ERR_STATE otherwise). */
 ow_status ow_get_intermediate(ow_context *ctx, int32_t cascade, float *out);
 
 /* ---- host math: static funcs of WaveGenerator (wave_generator.gd:116-121), FP64 ---------------------- */
