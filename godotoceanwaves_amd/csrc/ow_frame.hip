@@ -1,7 +1,17 @@
 // ow_frame.hip -- product instantiations + launchers of the two per-frame kernels (gfx950 / MI355X).
+#include <hip/hip_ext.h>
+
 #include "ow_frame_kernels.h"
 
 namespace ow {
+
+// Launch with optional start/stop events bound to the dispatch packet itself (hipExtLaunchKernelGGL): their elapsed
+// time is the kernel's own begin -> end, the figure a rocprofv3 kernel trace reports.
+template <class K, class... A>
+static void launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const LaunchTiming &lt, A... args) {
+    if (lt.start) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, lt.start, lt.stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+}
 
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
@@ -14,26 +24,26 @@ static bool use_lp(int slots, int mode) {
     return (long)slots * N * plan_T(N) / 64 <= 1024;  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
 }
 template <int N>
-static hipError_t launch1(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+static hipError_t launch1(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     const int blocks = slots * (N / kWgRows);
     if (use_lp<N>(slots, mode)) {
-        hipLaunchKernelGGL((k_pass1_lp<N>), dim3(blocks, kLayers), dim3(plan_wg_threads(N)), 0, s, buf, args);
+        launch(k_pass1_lp<N>, dim3(blocks, kLayers), dim3(plan_wg_threads(N)), s, lt, buf, args);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((k_pass1<N>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
+    launch(k_pass1<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 template <int N>
-static hipError_t launch2(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+static hipError_t launch2(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (use_lp<N>(slots, mode)) {
         const int lp_blocks = slots * (N / plan_lp_rows(N));
-        if (buf.f32) hipLaunchKernelGGL((k_pass2_lp<N, true>), dim3(lp_blocks), dim3(plan_lp_threads(N)), 0, s, buf, args);
-        else hipLaunchKernelGGL((k_pass2_lp<N, false>), dim3(lp_blocks), dim3(plan_lp_threads(N)), 0, s, buf, args);
+        if (buf.f32) launch(k_pass2_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
+        else launch(k_pass2_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
         return hipGetLastError();
     }
     const int blocks = slots * (N / kWgRows);
-    if (buf.f32) hipLaunchKernelGGL((k_pass2<N, true>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
-    else hipLaunchKernelGGL((k_pass2<N, false>), dim3(blocks), dim3(plan_wg_threads(N)), 0, s, buf, args, DebugArgs{});
+    if (buf.f32) launch(k_pass2<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
+    else launch(k_pass2<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 
@@ -43,23 +53,23 @@ hipError_t launch_empty(hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     switch (n) {
-        case 128: return launch1<128>(slots, mode, args, buf, s);
-        case 256: return launch1<256>(slots, mode, args, buf, s);
-        case 512: return launch1<512>(slots, mode, args, buf, s);
-        case 1024: return launch1<1024>(slots, mode, args, buf, s);
-        case 2048: return launch1<2048>(slots, mode, args, buf, s);
+        case 128: return launch1<128>(slots, mode, args, buf, s, lt);
+        case 256: return launch1<256>(slots, mode, args, buf, s, lt);
+        case 512: return launch1<512>(slots, mode, args, buf, s, lt);
+        case 1024: return launch1<1024>(slots, mode, args, buf, s, lt);
+        case 2048: return launch1<2048>(slots, mode, args, buf, s, lt);
     }
     return hipErrorInvalidValue;
 }
-hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s) {
+hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     switch (n) {
-        case 128: return launch2<128>(slots, mode, args, buf, s);
-        case 256: return launch2<256>(slots, mode, args, buf, s);
-        case 512: return launch2<512>(slots, mode, args, buf, s);
-        case 1024: return launch2<1024>(slots, mode, args, buf, s);
-        case 2048: return launch2<2048>(slots, mode, args, buf, s);
+        case 128: return launch2<128>(slots, mode, args, buf, s, lt);
+        case 256: return launch2<256>(slots, mode, args, buf, s, lt);
+        case 512: return launch2<512>(slots, mode, args, buf, s, lt);
+        case 1024: return launch2<1024>(slots, mode, args, buf, s, lt);
+        case 2048: return launch2<2048>(slots, mode, args, buf, s, lt);
     }
     return hipErrorInvalidValue;
 }

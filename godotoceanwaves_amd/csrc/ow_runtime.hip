@@ -59,7 +59,7 @@ struct ow_context {
     int pass_num_cascades_remaining = 0;
     // timing: a pool of event triples so that timed ticks stay enqueued back to back
     bool timing = false;
-    std::vector<hipEvent_t> ev;  // 3 per timed batch: before pass 1, between, after pass 2
+    std::vector<hipEvent_t> ev;  // 4 per timed batch: start/stop of the pass-1 dispatch, start/stop of the pass-2 dispatch
     size_t ev_used = 0;
     double t1_ms = 0, t2_ms = 0;
     int t_launches = 0;
@@ -83,12 +83,12 @@ constexpr size_t kMaxTimedBatches = 4096;
 ow_status collect_timing(ow_context *c) {
     if (c->ev_used == 0) return OW_OK;
     OW_HIP(hipEventSynchronize(c->ev[c->ev_used - 1]));
-    for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
+    for (size_t i = 0; i + 4 <= c->ev_used; i += 4) {
         float a = 0, b = 0;
         OW_HIP(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
-        OW_HIP(hipEventElapsedTime(&b, c->ev[i + 1], c->ev[i + 2]));
-        c->t1_ms += a > c->ev_overhead_ms ? a - c->ev_overhead_ms : 0.0f;
-        c->t2_ms += b > c->ev_overhead_ms ? b - c->ev_overhead_ms : 0.0f;
+        OW_HIP(hipEventElapsedTime(&b, c->ev[i + 2], c->ev[i + 3]));
+        c->t1_ms += a;
+        c->t2_ms += b;
         c->t_launches += 1;
     }
     c->ev_used = 0;
@@ -96,17 +96,17 @@ ow_status collect_timing(ow_context *c) {
 }
 
 ow_status next_events(ow_context *c, hipEvent_t **out) {
-    if (c->ev_used + 3 > 3 * kMaxTimedBatches) {
+    if (c->ev_used + 4 > 4 * kMaxTimedBatches) {
         ow_status st = collect_timing(c);
         if (st != OW_OK) return st;
     }
-    while (c->ev.size() < c->ev_used + 3) {
+    while (c->ev.size() < c->ev_used + 4) {
         hipEvent_t e;
         OW_HIP(hipEventCreate(&e));
         c->ev.push_back(e);
     }
     *out = &c->ev[c->ev_used];
-    c->ev_used += 3;
+    c->ev_used += 4;
     return OW_OK;
 }
 
@@ -164,12 +164,10 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         if (c->timing) {
             ow_status st = next_events(c, &ev);
             if (st != OW_OK) return st;
-            OW_HIP(hipEventRecord(ev[0], c->stream));
         }
-        OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream));  // modulate + rows + transpose (:73-80)
-        if (ev) OW_HIP(hipEventRecord(ev[1], c->stream));
-        OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, c->stream));  // rows + unpack (:82-85)
-        if (ev) OW_HIP(hipEventRecord(ev[2], c->stream));
+        const ow::LaunchTiming t1{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}, t2{ev ? ev[2] : nullptr, ev ? ev[3] : nullptr};
+        OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t1));  // modulate + rows + transpose (:73-80)
+        OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t2));  // rows + unpack (:82-85)
     }
     return OW_OK;
 }
@@ -501,32 +499,11 @@ ow_status ow_timing_enable(ow_context *c, int32_t enable) {
         ow_status st = collect_timing(c);
         if (st != OW_OK) return st;
     }
-    if (enable && !c->timing) {
-        // calibrate: an event pair around an empty kernel measures marker processing + dispatch latency, which a
-        // rocprofv3 kernel trace does not count as kernel time; the minimum of a few tries is subtracted later
-        OW_HIP(hipSetDevice(c->device));
-        hipEvent_t e0, e1;
-        OW_HIP(hipEventCreate(&e0));
-        OW_HIP(hipEventCreate(&e1));
-        float best = 1e9f;
-        for (int i = 0; i < 8; ++i) {
-            OW_HIP(hipEventRecord(e0, c->stream));
-            OW_HIP(ow::launch_empty(c->stream));
-            OW_HIP(hipEventRecord(e1, c->stream));
-            OW_HIP(hipEventSynchronize(e1));
-            float ms = 0;
-            OW_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (i > 1 && ms < best) best = ms;
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        c->ev_overhead_ms = best < 1e8f ? best : 0.0f;
-    }
     c->timing = enable != 0;
     return OW_OK;
 }
 
-float ow_timing_overhead_ms(const ow_context *c) { return c ? c->ev_overhead_ms : 0.0f; }
+float ow_timing_overhead_ms(const ow_context *c) { return c ? c->ev_overhead_ms : 0.0f; }  // always 0 (kept for ABI stability)
 
 ow_status ow_timing_read(ow_context *c, float *p1, float *p2, int32_t *launches, int32_t reset) {
     if (!c) return fail(OW_ERR_INVALID, "null context");

@@ -163,13 +163,12 @@ double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
-/* Average duration (ms) of the two frame kernels over the launches made since the last reset,
- * measured with hipEvents on the context's stream.  Enable first; enabling adds two event records
- * per launch, so throughput runs keep it off. */
+/* Average duration (ms) of the two frame kernels over the launches made since the last reset, in situ: while
+ * enabled, every launch carries start/stop hipEvents bound to its own dispatch packet (hipExtLaunchKernel), so the
+ * figure is the kernel's begin -> end exactly as a rocprofv3 kernel trace reports it.  Throughput runs keep it off. */
 ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
-/* What an event pair around an EMPTY kernel measures on this stream (marker processing + dispatch latency);
- * calibrated by ow_timing_enable and already subtracted from the averages of ow_timing_read. */
+/* Obsolete (always 0): the timing events are bound to the dispatch packets and need no calibration. */
 float ow_timing_overhead_ms(const ow_context *ctx);
 
 /* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
