@@ -6,12 +6,12 @@
 // which tests/emul/ uses to step 64 emulated lanes through the identical code on a
 // machine without a GPU (test infrastructure; never part of the product path).
 //
-// Design: one wavefront owns one map row with all four packed
-// spectra ("layers", spectrum_modulate.glsl:84-89).  A row transform of length N is a
-// Stockham auto-sort DIF FFT, radix 16 x 16 x {-,2,4,8}, 16 points per lane held in
-// registers, with two LDS exchanges between the radix passes; N/16 lanes cooperate on
-// a row (so a wave carries 64/(N/16) rows when N < 1024).  No workgroup barrier exists
-// anywhere: a workgroup IS one wave, and LDS operations of one wave execute in order.
+// Design: N/16 lanes own one map row, 16 points per lane, and transform its four packed
+// spectra ("layers", spectrum_modulate.glsl:84-89) one after the other (or, in the layer-parallel kernels, one layer
+// per lane group).  A row transform of length N is a Stockham auto-sort DIF FFT, radix 16 x 16 x {-,2,4,8}, butterflies
+// in registers; the first exchange goes through LDS, the last one (N = 512, 1024) through the row-swap instructions.
+// A wave carries 64/(N/16) rows when N < 1024; at N = 2048 a row spans two waves.  A workgroup is the lanes of 8
+// consecutive rows; its barriers order LDS traffic only.
 #pragma once
 
 #include <stdint.h>
