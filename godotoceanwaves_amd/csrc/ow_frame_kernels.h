@@ -45,11 +45,42 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// sync between the lanes that share a row's LDS region
+// Sync between the lanes that share a row's LDS region.  N <= 1024: the row is one wave, whose DS instructions execute
+// in order -- nothing to wait for, only the compiler's ordering is pinned.  N = 2048: the row is a PAIR of waves; they
+// rendezvous through two LDS words (each wave publishes a monotonically increasing epoch after its own LDS traffic has
+// completed, and polls its partner's) instead of an s_barrier, which would put all 16 waves of the block in lockstep
+// at every exchange although only pairs exchange data.
 template <int N>
-__device__ __forceinline__ void row_sync() {
-    if constexpr (plan_row_spans_waves(N)) lds_barrier();
-    else wave_sync();
+struct RowSync {
+    typedef __attribute__((address_space(3))) int lds_int;
+    volatile lds_int *mine = nullptr, *partner = nullptr;
+    int epoch = 0;
+    // flags: two ints per pair (zeroed by init_row_sync); pair = index of the row (or row x layer) inside the block
+    __device__ __forceinline__ void attach(int *flags, int pair, int wave_in_pair) {
+        if constexpr (plan_row_spans_waves(N)) {
+            mine = (volatile lds_int *)(flags + 2 * pair + wave_in_pair);
+            partner = (volatile lds_int *)(flags + 2 * pair + (wave_in_pair ^ 1));
+        }
+    }
+    __device__ __forceinline__ void sync() {
+        if constexpr (plan_row_spans_waves(N)) {
+            ++epoch;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // s_waitcnt lgkmcnt(0): my LDS reads/writes are done
+            *mine = epoch;
+            // bounded: a partner that never arrives (a bug) must not hang the device; ~2^20 polls is >100 ms
+            for (int spin = 0; __builtin_amdgcn_readfirstlane(*partner) < epoch && spin < (1 << 20); ++spin) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        } else {
+            wave_sync();
+        }
+    }
+};
+constexpr int plan_sync_flag_cplx(int N, int pairs) { return plan_row_spans_waves(N) ? (pairs + 3) / 4 * 4 : 0; }  // 2 ints = 1 cplx per pair, padded
+template <int N>
+__device__ __forceinline__ void init_row_sync(int *flags, int pairs) {
+    if constexpr (plan_row_spans_waves(N)) {
+        if ((int)threadIdx.x < 2 * pairs) flags[threadIdx.x] = 0;  // made visible by the block barrier of load_twiddles
+    }
 }
 
 __device__ __forceinline__ unsigned xcc_id() {
@@ -74,22 +105,22 @@ __device__ __forceinline__ void load_twiddles(cplx *tw_lds, const cplx *__restri
 // (BLOCK_GATE: a workgroup barrier right before the first write into the row regions -- pass 1 uses it when
 // other waves may still be draining the previous layer's staged rows out of them)
 template <int N, bool BLOCK_GATE = false>
-__device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw) {
+__device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RowSync<N> &rs) {
     fft_stage_compute<N, 0>(d, t, tw);
     if constexpr (BLOCK_GATE) lds_barrier();
     fft_stage_write<N, 0>(d, t, lds_row);
-    row_sync<N>();
+    rs.sync();
     fft_stage_read<N, 1>(d, t, lds_row);
-    row_sync<N>();
+    rs.sync();
     fft_stage_compute<N, 1>(d, t, tw);
     if constexpr (plan_S(N) == 3) {
         if constexpr (plan_lane_exchange(N)) {
             fft_lane_exchange<N>(d);  // row-swap instructions, no LDS
         } else {
             fft_stage_write<N, 1>(d, t, lds_row);
-            row_sync<N>();
+            rs.sync();
             fft_stage_read<N, 2>(d, t, lds_row);
-            row_sync<N>();
+            rs.sync();
         }
         fft_stage_compute<N, 2>(d, t, tw);
     }
@@ -143,7 +174,7 @@ __device__ __forceinline__ void write_stamps(const unsigned long long *ts, const
 template <int N, int VAR = 0, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
     constexpr int Tn = plan_T(N), P = kP;
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;  // table first: its DS offsets then fit the 16-bit immediate field
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
@@ -151,6 +182,10 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
     constexpr bool kLoad = (VAR & 1) == 0;
@@ -211,14 +246,14 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
         OW_SCHED_FENCE();
         OW_STAMP(2 + 3 * L, d[0].x)
         if constexpr (kFft) {
-            if (kDefer && L > 0) row_ifft<N, true>(d, t, lds_row, tw_lds);
-            else row_ifft<N, false>(d, t, lds_row, tw_lds);
+            if (kDefer && L > 0) row_ifft<N, true>(d, t, lds_row, tw_lds, rs);
+            else row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
         } else if (kDefer && L > 0) {
             lds_barrier();
         }
         OW_STAMP(3 + 3 * L, d[0].x)
         if (kStore || dbg.never_true) {
-            row_sync<N>();  // the row's exchange reads are done before its region becomes the staging image
+            rs.sync();  // the row's exchange reads are done before its region becomes the staging image
             Pass1<N>::stage_write(d, t, lds_row);
             lds_barrier();
             if (L == kLayers - 1) Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);  // nothing left to hide under
@@ -243,13 +278,17 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
 template <int N, bool F32, int VAR = 0, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers buf, FrameArgs args, DebugArgs dbg) {
     constexpr int Tn = plan_T(N), P = kP;
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;  // table first: its DS offsets then fit the 16-bit immediate field
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
     constexpr bool kLoad = (VAR & 1) == 0;
@@ -285,7 +324,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
         fetch(l2, 2);
         load_twiddles<N>(tw_lds, buf.tw);
         OW_STAMP(1, l2[0].x)
-        if constexpr (kFft) row_ifft<N>(l2, t, lds_row, tw_lds);
+        if constexpr (kFft) row_ifft<N>(l2, t, lds_row, tw_lds, rs);
         cplx l3[P];
         uint32_t foam_pk[P / 2];
         fetch(l3, 3);
@@ -295,7 +334,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 #pragma unroll
             for (int j = 0; j < P / 2; ++j) foam_pk[j] = 0;
         }
-        if constexpr (kFft) row_ifft<N>(l3, t, lds_row, tw_lds);
+        if constexpr (kFft) row_ifft<N>(l3, t, lds_row, tw_lds, rs);
         OW_STAMP(2, l3[0].x)
         Pass2<N>::template after_layer3<F32 && kStore>(l3, l2, foam_pk, gy_foam, tex, cf, f32_c);
         if (kStore || dbg.never_true) Pass2<N>::store_foam(foam_pk, t, xp, foam_c);
@@ -306,7 +345,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     {
         cplx l1[P];
         fetch(l1, 1);
-        if constexpr (kFft) row_ifft<N>(l1, t, lds_row, tw_lds);
+        if constexpr (kFft) row_ifft<N>(l1, t, lds_row, tw_lds, rs);
         if (kStore || dbg.never_true) {
             Pass2<N>::template after_layer1<F32, AUX_O>(l1, dhx_dx, gy_foam, tex, norm_c, f32_c);
         } else {
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     {
         cplx l0[P];
         fetch(l0, 0);
-        if constexpr (kFft) row_ifft<N>(l0, t, lds_row, tw_lds);
+        if constexpr (kFft) row_ifft<N>(l0, t, lds_row, tw_lds, rs);
         OW_STAMP(3, l0[0].x)
         if (kStore || dbg.never_true) {
             Pass2<N>::template after_layer0<F32, AUX_O>(l0, hz, t, xp, tex, disp_c, f32_c);
@@ -349,13 +388,17 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 template <int N, int AUX_T = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffers buf, FrameArgs args) {
     constexpr int Tn = plan_T(N), P = kP;
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
     const int L = blockIdx.y;
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
@@ -380,8 +423,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
         default: Pass1<N>::template layer_input<3>(d, h, ik, t, ky, dkx); break;
     }
     OW_SCHED_FENCE();
-    row_ifft<N>(d, t, lds_row, tw_lds);
-    row_sync<N>();
+    row_ifft<N>(d, t, lds_row, tw_lds, rs);
+    rs.sync();
     Pass1<N>::stage_write(d, t, lds_row);
     lds_barrier();
     Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
@@ -397,7 +440,7 @@ constexpr int plan_lp_lds_cplx(int N) { return plan_region_cplx(N) * plan_lp_row
 template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
 __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffers buf, FrameArgs args) {
     constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N)];
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + plan_sync_flag_cplx(N, plan_lp_rows(N) * kLayers)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
@@ -415,14 +458,18 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
     const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
     auto region = [&](int row, int layer) { return rows_lds + (layer * ROWS + row) * plan_region_cplx(N); };
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, ROWS * kLayers);
 
     cplx d[P];
     Pass2<N>::template load_layer<AUX_T>(d, t, xp, g, T_c);
     // this group's quarter of the lane's foam values (o = 4g .. 4g+3): 8 bytes of the lane's 32
     const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
     load_twiddles<N>(tw_lds, buf.tw);
-    row_ifft<N>(d, t, region(r, g), tw_lds);
-    row_sync<N>();
+    row_ifft<N>(d, t, region(r, g), tw_lds, rs);
+    rs.sync();
     {
         cplx *mine = region(r, g);
 #pragma unroll
