@@ -168,6 +168,28 @@ def test_full_size_properties(n):
             assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, name
 
 
+@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (2048, [0, 2])])
+def test_batched_launches_match_oracle(n, ids):
+    """More cascades than one pair of launches takes (the runtime batches at 4 Mi texels and reuses the scratch
+    intermediate between batches): every cascade still matches the oracle, two frames."""
+    gen, params = make_gen(n, ids)
+    og = H.oracle_generator(n, ids)
+    for frame in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    for i in range(len(ids)):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+    with pytest.raises(_lib.OceanWavesError):
+        gen.get_intermediate(len(ids) - 1)   # first batch's scratch has been overwritten by the last batch (update_all drains highest index first)
+    assert gen.get_intermediate(0).shape == (4, n, n, 2)
+
+
 def test_invalid_arguments_are_errors():
     gen, params = make_gen(256, [0, 1], debug=False)
     L = _lib.load()
