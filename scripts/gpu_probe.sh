@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 300 ./tools/kbench 4 200 0 2>&1 | grep -E "stagger|pass1 var  0|aux T=0 H=0|^tick  " > gpurun_out/kbench_stagger.log; cat gpurun_out/kbench_stagger.log
+for bt in 4194304 2097152 1048576; do for c in 4 8; do echo "batch texels $bt cascades $c"; OW_BATCH_TEXELS=$bt timeout 120 python scripts/drive.py --map-size 1024 --cascades $c --frames 1500 --warmup 1500; done; done 2>&1 | tee gpurun_out/batch.log
