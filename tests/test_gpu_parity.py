@@ -190,6 +190,36 @@ def test_batched_launches_match_oracle(n, ids):
     assert gen.get_intermediate(0).shape == (4, n, n, 2)
 
 
+def _edge_cases():
+    from edge_presets import edge_presets
+    return sorted(edge_presets().items())
+
+
+@pytest.mark.parametrize("name,preset", _edge_cases(), ids=[k for k, _ in _edge_cases()])
+def test_parameter_range_edges_match_oracle(name, preset):
+    """range ends of every exported parameter, non-square tiles, wrapping seeds, t = 0 and the largest phases (256^2)"""
+    n = 256
+    gen = WaveGenerator()
+    gen.map_size, gen.debug_f32 = n, True
+    gen.init_gpu(2)
+    params = [WaveCascadeParameters(**preset)]
+    og = O.Generator(n, 1, DEPTH)
+    H.set_params(og.params[0], preset)
+    for _ in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    f32, ref = gen.get_maps_f32(0), og.f32(0)
+    assert np.isfinite(f32).all()
+    for c, cname in enumerate(H.CHANNELS):
+        if cname == "foam":
+            assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, cname
+        elif np.abs(ref[..., c]).max() > 0:
+            assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, cname
+    disp, norm = gen.get_maps(0)
+    assert H.quantisation_exact(f32, disp, norm)
+
+
 def test_invalid_arguments_are_errors():
     gen, params = make_gen(256, [0, 1], debug=False)
     L = _lib.load()

@@ -37,6 +37,29 @@ def test_oracle_is_bit_exact_against_the_reference_shaders(n, ci, frames):
         assert np.array_equal(rc.normal, g.normal(0))                                            # incl. the FP16 foam recurrence
 
 
+def _edge_cases():
+    from edge_presets import edge_presets
+    return sorted(edge_presets().items())
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libglsl_ref.so not built (needs the reference checkout)")
+@pytest.mark.parametrize("name,preset", _edge_cases(), ids=[k for k, _ in _edge_cases()])
+def test_oracle_is_bit_exact_at_the_edges_of_the_parameter_ranges(name, preset):
+    """range ends of every exported parameter, non-square tiles, wrapping seeds, t = 0 and the largest phases"""
+    n = 128
+    rc = R.RefCascade(n, preset)
+    g = O.Generator(n, 1, DEPTH)
+    H.set_params(g.params[0], preset)
+    for _ in range(2):
+        rc.update(UPDATE_DELTA)
+        g.update_all(UPDATE_DELTA)
+    assert np.array_equal(rc.spectrum.view(np.uint32), g.spectrum(0).view(np.uint32))
+    assert np.array_equal(rc.fft[1].view(np.uint32), g.fft_half1(0).view(np.uint32))
+    assert np.array_equal(rc.displacement, g.displacement(0))
+    assert np.array_equal(rc.normal, g.normal(0))
+    assert np.isfinite(g.spectrum(0)).all()
+
+
 def test_golden_fixtures_exist():
     assert len(GOLDEN) >= 3, "tests/golden/*.npz missing: run tests/golden/make_golden.py where /root/reference exists"
 
