@@ -49,6 +49,9 @@ SIGNATURES = {
     "ow_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
     "ow_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ow_set_normal_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ow_readback_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "ow_readback_wait": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_void_p)]),
+    "ow_sample_surface": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ow_get_maps_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ow_get_spectrum": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ow_get_intermediate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

@@ -11,11 +11,13 @@ LIB = os.path.join(HERE, "libocean_waves.so")
 ARCH = "gfx950"
 
 # translation unit -> extra flags.  ow_spectrum.hip is built with FP contraction off: its omega(k)
-# plane must be bit-identical to the oracle's.
+# plane must be bit-identical to the oracle's; ow_consumer.hip likewise (the sampling
+# arithmetic is checked operation for operation).
 UNITS = {
     "ow_frame.hip": [],
     "ow_spectrum.hip": ["-ffp-contract=off"],
     "ow_runtime.hip": [],
+    "ow_consumer.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -24,6 +24,21 @@ struct LaunchTiming {
     hipEvent_t start = nullptr, stop = nullptr;
 };
 
+// consumer-side sampling (ow_consumer.hip); SurfaceSample is layout-identical to ow_surface_sample in include/ocean_waves.h
+struct SurfaceScales {
+    float s[8][4];  // map_scales[i] = (1/tile_length.x, 1/tile_length.y, displacement_scale, normal_scale), water.gd:105-109
+};
+struct SurfaceSample {
+    float displacement[3];
+    float gradient[2];
+    float gradient_scaled[2];
+    float foam;
+    float normal_factor, foam_factor, scale_factor;
+    int32_t spray_active;
+};
+hipError_t launch_sample_surface(int n, int cascades, const DeviceBuffers &buf, const float *xz_dev, int count,
+                                 const SurfaceScales &scales, SurfaceSample *out_dev, hipStream_t s);
+
 bool supported_map_size(int n);
 hipError_t launch_spectrum(int n, int cascade, const SpectrumPC &pc, const DeviceBuffers &buf, hipStream_t s);
 hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,

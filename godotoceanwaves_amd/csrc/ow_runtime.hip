@@ -68,6 +68,15 @@ struct ow_context {
     // last batch that was launched (for ow_probe_kernel_times)
     ow::FrameArgs last_args{};
     int last_count = 0;
+    // hand-off to a host consumer (ow_readback_*): device snapshot + page-locked staging, one slot per layer and map
+    hipStream_t copy_stream = nullptr;
+    ow::u16x4 *snap_dev = nullptr, *snap_host = nullptr;  // [2 maps][layers][N][N]
+    hipEvent_t snap_ready[OW_MAX_CASCADES] = {}, copy_done[OW_MAX_CASCADES] = {};
+    bool copy_pending[OW_MAX_CASCADES] = {};
+    // ow_sample_surface scratch (grow-only)
+    float *query_xz = nullptr;
+    ow::SurfaceSample *query_out = nullptr;
+    int query_capacity = 0;
 };
 
 namespace {
@@ -303,6 +312,16 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->buf.foam);
     (void)hipFree(c->buf.f32);
     (void)hipFree(c->tw_dev);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipFree(c->snap_dev);
+    if (c->snap_host) (void)hipHostFree(c->snap_host);
+    for (auto &e : c->snap_ready)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->copy_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    (void)hipFree(c->query_xz);
+    (void)hipFree(c->query_out);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -386,6 +405,83 @@ ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {
     const size_t bytes = plane(c) * sizeof(ow::u16x4);
     if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
     if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipStreamSynchronize(c->stream));
+    return OW_OK;
+}
+
+ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (mask == 0 || (mask >> c->layers) != 0) return fail(OW_ERR_INVALID, "cascade_mask 0x%x selects no layer or one >= %d", mask, c->layers);
+    OW_HIP(hipSetDevice(c->device));
+    const size_t pl = plane(c), L = (size_t)c->layers, bytes = pl * sizeof(ow::u16x4);
+    if (!c->copy_stream) {  // first use: second stream, snapshot planes, page-locked staging, events
+        OW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (hipMalloc((void **)&c->snap_dev, 2 * L * bytes) != hipSuccess) return fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for the readback snapshot", 2 * L * bytes);
+        if (hipHostMalloc((void **)&c->snap_host, 2 * L * bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(OW_ERR_NOMEM, "hipHostMalloc of %zu bytes failed for the readback staging", 2 * L * bytes);
+        for (size_t i = 0; i < L; ++i) {
+            OW_HIP(hipEventCreateWithFlags(&c->snap_ready[i], hipEventDisableTiming));
+            OW_HIP(hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        }
+    }
+    for (int i = 0; i < c->layers; ++i) {
+        if (!((mask >> i) & 1u)) continue;
+        ow::u16x4 *sd = c->snap_dev + (size_t)i * pl, *sn = c->snap_dev + (L + i) * pl;
+        ow::u16x4 *hd = c->snap_host + (size_t)i * pl, *hn = c->snap_host + (L + i) * pl;
+        // the snapshot slot may still be feeding an earlier PCIe copy
+        if (c->copy_pending[i]) OW_HIP(hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
+        OW_HIP(hipMemcpyAsync(sd, c->buf.disp + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
+        OW_HIP(hipMemcpyAsync(sn, c->buf.norm + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
+        OW_HIP(hipEventRecord(c->snap_ready[i], c->stream));
+        OW_HIP(hipStreamWaitEvent(c->copy_stream, c->snap_ready[i], 0));
+        OW_HIP(hipMemcpyAsync(hd, sd, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        OW_HIP(hipMemcpyAsync(hn, sn, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        OW_HIP(hipEventRecord(c->copy_done[i], c->copy_stream));
+        c->copy_pending[i] = true;
+    }
+    return OW_OK;
+}
+
+ow_status ow_readback_wait(ow_context *c, int32_t cascade, const void **disp, const void **norm) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    if (!c->copy_stream || !c->copy_pending[cascade]) return fail(OW_ERR_STATE, "no readback of cascade %d is outstanding", cascade);
+    OW_HIP(hipSetDevice(c->device));
+    OW_HIP(hipEventSynchronize(c->copy_done[cascade]));
+    c->copy_pending[cascade] = false;
+    const size_t pl = plane(c), L = (size_t)c->layers;
+    if (disp) *disp = c->snap_host + (size_t)cascade * pl;
+    if (norm) *norm = c->snap_host + (L + cascade) * pl;
+    return OW_OK;
+}
+
+ow_status ow_sample_surface(ow_context *c, const float *xz, int32_t count, const float *map_scales, int32_t num_cascades,
+                            ow_surface_sample *out) {
+    static_assert(sizeof(ow_surface_sample) == sizeof(ow::SurfaceSample) && sizeof(ow_surface_sample) == 48, "record layout");
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (count < 0) return fail(OW_ERR_INVALID, "count must be >= 0");
+    if (num_cascades < 1 || num_cascades > c->cascades) return fail(OW_ERR_INVALID, "num_cascades %d outside [1,%d]", num_cascades, c->cascades);
+    if (count == 0) return OW_OK;
+    if (!xz || !map_scales || !out) return fail(OW_ERR_INVALID, "null argument");
+    OW_HIP(hipSetDevice(c->device));
+    if (count > c->query_capacity) {
+        (void)hipFree(c->query_xz);
+        (void)hipFree(c->query_out);
+        c->query_xz = nullptr;
+        c->query_out = nullptr;
+        c->query_capacity = 0;
+        const int cap = std::max(count, 4096);
+        if (hipMalloc((void **)&c->query_xz, (size_t)cap * 2 * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&c->query_out, (size_t)cap * sizeof(ow::SurfaceSample)) != hipSuccess)
+            return fail(OW_ERR_NOMEM, "hipMalloc failed for %d query points", cap);
+        c->query_capacity = cap;
+    }
+    ow::SurfaceScales sc;
+    std::memset(&sc, 0, sizeof(sc));
+    std::memcpy(sc.s, map_scales, (size_t)num_cascades * 4 * sizeof(float));
+    OW_HIP(hipMemcpyAsync(c->query_xz, xz, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    OW_HIP(ow::launch_sample_surface(c->n, num_cascades, c->buf, c->query_xz, count, sc, c->query_out, c->stream));
+    OW_HIP(hipMemcpyAsync(out, c->query_out, (size_t)count * sizeof(ow::SurfaceSample), hipMemcpyDeviceToHost, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
     return OW_OK;
 }

@@ -212,6 +212,38 @@ class WaveGenerator:
         assert a.shape == (self.map_size, self.map_size, 4)
         _lib.check(self._lib.ow_set_normal_map(self.context, cascade, a.ctypes.data))
 
+    # ---- hand-off to a host-side consumer: the bytes for RenderingDevice.texture_update (water.gd:95-100) --------
+    def readback_begin(self, cascades):
+        """Start the asynchronous copy of the given layers (iterable of indices) into the context's page-locked
+        staging memory; returns at once, later updates overlap the PCIe transfer."""
+        mask = 0
+        for i in cascades:
+            mask |= 1 << int(i)
+        _lib.check(self._lib.ow_readback_begin(self.context, mask))
+
+    def readback_wait(self, cascade):
+        """(displacement, normal) of one layer as float16 [N][N][4] VIEWS of the staging memory: valid until the next
+        readback_begin of that layer (or free())."""
+        d, m = C.c_void_p(), C.c_void_p()
+        _lib.check(self._lib.ow_readback_wait(self.context, cascade, C.byref(d), C.byref(m)))
+        n = self.map_size
+        view = lambda p: np.frombuffer((C.c_uint16 * (n * n * 4)).from_address(p.value), np.float16).reshape(n, n, 4)
+        return view(d), view(m)
+
+    # ---- consumer-side sampling on the device (water.gdshader:27-39,72-82; sea_spray_particle.gdshader:78-96) ----
+    SURFACE_SAMPLE = np.dtype([("displacement", np.float32, 3), ("gradient", np.float32, 2), ("gradient_scaled", np.float32, 2),
+                               ("foam", np.float32), ("normal_factor", np.float32), ("foam_factor", np.float32),
+                               ("scale_factor", np.float32), ("spray_active", np.int32)])
+
+    def sample_surface(self, world_xz, map_scales):
+        """Evaluate the water vertex/fragment sums and the sea-spray spawn mask at world points [P][2] (x, z);
+        map_scales [C][4] as built by Water.map_scales() (water.gd:105-109).  Returns a structured array."""
+        xz = np.ascontiguousarray(world_xz, np.float32).reshape(-1, 2)
+        sc = np.ascontiguousarray(map_scales, np.float32).reshape(-1, 4)
+        out = np.zeros(len(xz), self.SURFACE_SAMPLE)
+        _lib.check(self._lib.ow_sample_surface(self.context, xz.ctypes.data, len(xz), sc.ctypes.data, len(sc), out.ctypes.data))
+        return out
+
     def get_maps_f32(self, cascade):
         out = np.empty((self.map_size, self.map_size, 8), np.float32)
         _lib.check(self._lib.ow_get_maps_f32(self.context, cascade, out.ctypes.data))

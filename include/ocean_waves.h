@@ -142,6 +142,41 @@ ow_status ow_get_maps(ow_context *ctx, int32_t cascade, void *displacement_rgba1
  * device pointer does not change the simulation. */
 ow_status ow_set_normal_map(ow_context *ctx, int32_t cascade, const void *normal_rgba16f);
 
+/* ---- hand-off to a host-side consumer ------------------------------------------- */
+
+/* Asynchronous readback of finished layers into page-locked host memory owned by the context: the bytes a
+ * Godot-side shim passes to RenderingDevice.texture_update(tex, layer, bytes) (the maps are created with
+ * TEXTURE_USAGE_CAN_UPDATE_BIT, wave_generator.gd:34-35 / render_context.gd:76-85).  `cascade_mask` bit i selects
+ * layer i.  ow_readback_begin snapshots the selected layers in stream order (device-to-device, after everything
+ * enqueued so far) and starts the PCIe copy on a second stream; it does not block, and later ow_update / ow_process
+ * calls run concurrently with the copy.  ow_readback_wait blocks until the copy of one layer has landed and returns
+ * pointers to N*N*8 bytes each (row-major RGBA16F); they stay valid until the next ow_readback_begin that selects
+ * the same layer, or ow_destroy.  OW_ERR_STATE if no readback of that layer is outstanding. */
+ow_status ow_readback_begin(ow_context *ctx, uint32_t cascade_mask);
+ow_status ow_readback_wait(ow_context *ctx, int32_t cascade, const void **displacement_rgba16f, const void **normal_rgba16f);
+
+/* ---- consumer-side sampling on the device ----------------------------------- */
+
+/* What the reference's consumers evaluate at one world-space point (x, z) from the two array textures; texture() is
+ * GL_LINEAR + GL_REPEAT with exact FP32 weights.  map_scales[i] = (1/tile_length.x, 1/tile_length.y,
+ * displacement_scale, normal_scale) as built by water.gd:105-109. */
+typedef struct ow_surface_sample {
+    float displacement[3];    /* sum_i texture(displacements, vec3(xz*scales_i.xy, i)).xyz * scales_i.z
+                                 (water.gdshader:31-37, sea_spray_particle.gdshader:103-108) */
+    float gradient[2];        /* sum_i texture(normals, ...).xy, unscaled (sea_spray_particle.gdshader:80-82) */
+    float gradient_scaled[2]; /* sum_i texture(normals, ...).xy * scales_i.w (water.gdshader:81, bilinear branch) */
+    float foam;               /* sum_i texture(normals, ...).w */
+    float normal_factor;      /* sea_spray_particle.gdshader:85: mix(0.25, 1, min((normal.y - 0.92) / 0.07, 1)) */
+    float foam_factor;        /* :86: mix(0.25, 1, min((foam - 0.9) / 0.1, 1)) */
+    float scale_factor;       /* :89 SCALE_FACTOR = normal_factor * foam_factor */
+    int32_t spray_active;     /* :88 ACTIVE = normal_factor in [0,1] && foam > 0.9: the sea-spray spawn mask */
+} ow_surface_sample;
+
+/* Samples layers 0..num_cascades-1 at `count` points (world_xz = x0,z0,x1,z1,...; map_scales = 4 floats per cascade;
+ * all host pointers) after everything enqueued so far, and writes `count` records.  Synchronises. */
+ow_status ow_sample_surface(ow_context *ctx, const float *world_xz, int32_t count, const float *map_scales,
+                            int32_t num_cascades, ow_surface_sample *out);
+
 /* ---- parity / debug ------------------------------------------------------------------------------ */
 
 /* 8 FP32 channels per texel before FP16 quantisation: [hx, hy, hz, grad_x, grad_y, dhx_dx, foam, jacobian],

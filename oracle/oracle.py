@@ -77,11 +77,28 @@ def lib(native=False):
         fn.argtypes = [C.c_void_p, C.c_int]
     L.owo_generator_set_normal.argtypes = [C.c_void_p, C.c_int, u16p]
     L.owo_num_threads.restype = C.c_int
+    L.owo_sample_surface.argtypes = [C.c_int, C.c_int, u16p, u16p, f32p, f32p, C.c_int, C.c_void_p]
     _libs[native] = L
     return L
 
 
 # ---- convenience wrappers (NumPy in / NumPy out) ----------------------------------------------
+
+SURFACE_SAMPLE = np.dtype([("displacement", np.float32, 3), ("gradient", np.float32, 2), ("gradient_scaled", np.float32, 2),
+                           ("foam", np.float32), ("normal_factor", np.float32), ("foam_factor", np.float32),
+                           ("scale_factor", np.float32), ("spray_active", np.int32)])
+
+
+def sample_surface(displacements, normals, map_scales, world_xz):
+    """displacements / normals: [C][N][N][4] FP16 (or their uint16 bits); map_scales [C][4]; world_xz [P][2]"""
+    d = np.ascontiguousarray(np.asarray(displacements).view(np.uint16))
+    m = np.ascontiguousarray(np.asarray(normals).view(np.uint16))
+    sc = np.ascontiguousarray(map_scales, np.float32)
+    xz = np.ascontiguousarray(world_xz, np.float32)
+    out = np.zeros(len(xz), SURFACE_SAMPLE)
+    lib().owo_sample_surface(d.shape[1], len(sc), d, m, sc, xz, len(xz), out.ctypes.data)
+    return out
+
 
 def jonswap_alpha(U, F_m):
     return lib().owo_jonswap_alpha(U, F_m)

@@ -493,3 +493,57 @@ const float *owo_generator_f32(const owo_generator *g, int c) { return g->f32 + 
 void owo_generator_set_normal(owo_generator *g, int c, const uint16_t *normal) {
     memcpy(g->normal + (size_t)g->n * g->n * 4 * c, normal, (size_t)g->n * g->n * 4 * sizeof(uint16_t));
 }
+
+/* ---- consumer side: what the spatial and particle shaders read back --------------- */
+
+/* texture(sampler2DArray, vec3(uv, layer)) with GL_LINEAR + GL_REPEAT on an n x n RGBA16F layer (OpenGL 4.6 core
+ * spec 8.14.2 / Vulkan spec 16.8: unnormalised coordinate u*n - 0.5, i0 = floor, weights = fract, exact FP32
+ * weights -- real texture units quantise them to 8 bits, which the reference does not pin) */
+static void texture_linear_repeat(const uint16_t *layer, int n, float u, float v, float out[4]) {
+    float un = u * (float)n - 0.5f, vn = v * (float)n - 0.5f;
+    float fi = floorf(un), fj = floorf(vn);
+    float a = un - fi, b = vn - fj;
+    long i0 = (long)fi % n, j0 = (long)fj % n;
+    if (i0 < 0) i0 += n;
+    if (j0 < 0) j0 += n;
+    long i1 = (i0 + 1) % n, j1 = (j0 + 1) % n;
+    for (int k = 0; k < 4; ++k) {
+        float t00 = owo_f16_to_f32(layer[((size_t)j0 * n + i0) * 4 + k]), t10 = owo_f16_to_f32(layer[((size_t)j0 * n + i1) * 4 + k]);
+        float t01 = owo_f16_to_f32(layer[((size_t)j1 * n + i0) * 4 + k]), t11 = owo_f16_to_f32(layer[((size_t)j1 * n + i1) * 4 + k]);
+        out[k] = (t00 * (1.0f - a) + t10 * a) * (1.0f - b) + (t01 * (1.0f - a) + t11 * a) * b;
+    }
+}
+
+static float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; } /* GLSL mix() */
+
+void owo_sample_surface(int n, int num_cascades, const uint16_t *displacements, const uint16_t *normals,
+                        const float *map_scales, const float *world_xz, int count, owo_surface_sample *out) {
+    const size_t layer = (size_t)n * n * 4;
+    for (int p = 0; p < count; ++p) {
+        const float x = world_xz[2 * p], z = world_xz[2 * p + 1];
+        owo_surface_sample s;
+        memset(&s, 0, sizeof(s));
+        for (int i = 0; i < num_cascades; ++i) {
+            const float *scales = map_scales + 4 * i;
+            float d[4], g[4];
+            /* water.gdshader:33-36 and sea_spray_particle.gdshader:104-107 */
+            texture_linear_repeat(displacements + layer * i, n, x * scales[0], z * scales[1], d);
+            for (int k = 0; k < 3; ++k) s.displacement[k] += d[k] * scales[2];
+            /* sea_spray_particle.gdshader:81-82 (.xyw, unscaled); water.gdshader:81 (.xyw * vec3(scales.ww, 1)) */
+            texture_linear_repeat(normals + layer * i, n, x * scales[0], z * scales[1], g);
+            s.gradient[0] += g[0];
+            s.gradient[1] += g[1];
+            s.gradient_scaled[0] += g[0] * scales[3];
+            s.gradient_scaled[1] += g[1] * scales[3];
+            s.foam += g[3];
+        }
+        /* sea_spray_particle.gdshader:83-89 */
+        float nx = -s.gradient[0], ny = 1.0f, nz = -s.gradient[1];
+        float normal_y = ny * (1.0f / sqrtf(nx * nx + ny * ny + nz * nz));
+        s.normal_factor = mixf(0.25f, 1.0f, fminf((normal_y - 0.92f) / (0.99f - 0.92f), 1.0f));
+        s.foam_factor = mixf(0.25f, 1.0f, fminf((s.foam - 0.9f) / (1.0f - 0.9f), 1.0f));
+        s.spray_active = (s.normal_factor >= 0.0f && s.normal_factor <= 1.0f && s.foam > 0.9f) ? 1 : 0;
+        s.scale_factor = s.normal_factor * s.foam_factor;
+        out[p] = s;
+    }
+}

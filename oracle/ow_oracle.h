@@ -126,6 +126,19 @@ const float *owo_generator_f32(const owo_generator *g, int cascade);
 void owo_generator_set_normal(owo_generator *g, int cascade, const uint16_t *normal);
 int owo_num_threads(void);
 
+/* consumer side: water.gdshader:27-39,72-82 (bilinear branch) and sea_spray_particle.gdshader:78-96 at one point */
+typedef struct {
+    float displacement[3];
+    float gradient[2];
+    float gradient_scaled[2];
+    float foam;
+    float normal_factor, foam_factor, scale_factor;
+    int32_t spray_active;
+} owo_surface_sample;
+/* displacements / normals: [num_cascades][n][n][4] FP16 bits; map_scales: 4 floats per cascade (water.gd:105-109) */
+void owo_sample_surface(int n, int num_cascades, const uint16_t *displacements, const uint16_t *normals,
+                        const float *map_scales, const float *world_xz, int count, owo_surface_sample *out);
+
 #ifdef __cplusplus
 }
 #endif
