@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--prime-ms", type=float, default=300.0,
                     help="untimed clock priming before the W warm-up steps: the chip's DVFS needs tens of ms of load to reach its "
                          "steady clock, and a short run would otherwise time the ramp (0 disables)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsing the "
+                                                     "multi-rank control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (numbers are meaningless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline sample size in ticks (0 = auto, ~10-20 s)")
     return ap.parse_args()
@@ -83,10 +86,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
     from godotoceanwaves_amd import sharding
@@ -209,7 +217,9 @@ def main():
                                    f"delta=1/50 s, SURVEY 8d cascade table",
                        "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
                        "gather": ("every %d ticks (timed)" % args.gather_every) if (world > 1 and args.gather_every) else
-                                 ("final, untimed" if world > 1 else "none")},
+                                 ("final, untimed" if world > 1 else "none"),
+                       **({"rehearsal": f"backend={args.backend}, share_gpu={args.share_gpu}: NOT a measurement"}
+                          if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 500 python -m pytest tests/test_surface_sampling.py tests/test_readback.py tests/test_golden.py -m gpu -q -x 2>&1 | tail -25
-timeout 200 python scripts/pcie_rate.py 2>&1 | tee gpurun_out/pcie_rate.json | tail -5
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu 2>&1 | tail -12
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu --gather-every 100 2>&1 | tail -6
