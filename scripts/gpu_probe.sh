@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu 2>&1 | tail -12
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu --gather-every 100 2>&1 | tail -6
+timeout 300 python -m pytest tests/test_borrowed_resources.py -m gpu -q -x 2>&1 | tail -25
