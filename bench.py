@@ -63,7 +63,7 @@ def cpu_baseline(n, cascades):
     t0 = time.perf_counter()
     g.update_all(UPDATE_DELTA)
     one = time.perf_counter() - t0
-    frames = max(1, min(50, int(12.0 / max(one, 1e-3))))
+    frames = max(1, min(200, int(12.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(frames):
         g.update_all(UPDATE_DELTA)

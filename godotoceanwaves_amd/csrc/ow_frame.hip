@@ -47,12 +47,6 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
     return hipGetLastError();
 }
 
-__global__ void k_empty() {}
-hipError_t launch_empty(hipStream_t s) {
-    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s);
-    return hipGetLastError();
-}
-
 hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     switch (n) {
         case 128: return launch1<128>(slots, mode, args, buf, s, lt);

@@ -30,8 +30,7 @@ struct Stamp {
 };
 struct DebugArgs {
     Stamp *stamps;
-    int never_true;
-    int stagger;  // experiment: low byte = s_sleep(127) count for the delayed half of the blocks, next byte = which half
+    int never_true;  // keeps the results of the "no stores" variants alive
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -194,11 +193,6 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
 
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
-    if (dbg.stagger) {  // experiment: de-phase the blocks (all of them start together and would otherwise load / store in lockstep)
-        const int groups = (dbg.stagger >> 16) & 0xff, shift = (dbg.stagger >> 8) & 0xff, unit = dbg.stagger & 0xff;
-        const int g = (blockIdx.x >> shift) % groups;
-        for (int i = 0; i < g * unit; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 clocks = ~0.43 us
-    }
     const CascadeFrame cf = args.c[slot];
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);

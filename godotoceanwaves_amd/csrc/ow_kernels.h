@@ -43,7 +43,6 @@ bool supported_map_size(int n);
 hipError_t launch_spectrum(int n, int cascade, const SpectrumPC &pc, const DeviceBuffers &buf, hipStream_t s);
 hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,
                         const LaunchTiming &lt = LaunchTiming{});  // mode: 0 auto, 1 standard, 2 layer-parallel
-hipError_t launch_empty(hipStream_t s);  // one idle wave: calibrates event-bracket overhead
 hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,
                         const LaunchTiming &lt = LaunchTiming{});
 

@@ -57,13 +57,12 @@ struct ow_context {
     // generator state per invocation of update() (wave_generator.gd:13-15)
     ow_cascade_params *pass_parameters = nullptr;
     int pass_num_cascades_remaining = 0;
-    // timing: a pool of event triples so that timed ticks stay enqueued back to back
+    // timing: a pool of events so that timed ticks stay enqueued back to back
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 4 per timed batch: start/stop of the pass-1 dispatch, start/stop of the pass-2 dispatch
     size_t ev_used = 0;
     double t1_ms = 0, t2_ms = 0;
     int t_launches = 0;
-    float ev_overhead_ms = 0;  // what an event pair around an EMPTY kernel measures (subtracted from every interval)
     int slot_of[OW_MAX_CASCADES];  // launch slot of each cascade in the most recent batch, -1 if it was not in it
     // last batch that was launched (for ow_probe_kernel_times)
     ow::FrameArgs last_args{};
@@ -598,8 +597,6 @@ ow_status ow_timing_enable(ow_context *c, int32_t enable) {
     c->timing = enable != 0;
     return OW_OK;
 }
-
-float ow_timing_overhead_ms(const ow_context *c) { return c ? c->ev_overhead_ms : 0.0f; }  // always 0 (kept for ABI stability)
 
 ow_status ow_timing_read(ow_context *c, float *p1, float *p2, int32_t *launches, int32_t reset) {
     if (!c) return fail(OW_ERR_INVALID, "null context");

@@ -263,9 +263,6 @@ class WaveGenerator:
     def timing(self, enable):
         _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
 
-    def timing_overhead_ms(self):
-        return float(self._lib.ow_timing_overhead_ms(self.context))
-
     def probe_kernel_times(self, reps=50):
         """(pass1_ms, pass2_ms, cascades_per_launch): each kernel alone, `reps` back-to-back launches (benchmark probe;
         the extra pass-2 launches advance the foam state)"""

@@ -203,8 +203,6 @@ double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_
  * figure is the kernel's begin -> end exactly as a rocprofv3 kernel trace reports it.  Throughput runs keep it off. */
 ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
-/* Obsolete (always 0): the timing events are bound to the dispatch packets and need no calibration. */
-float ow_timing_overhead_ms(const ow_context *ctx);
 
 /* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
  * and then `reps` of pass 2 with the arguments of the most recent batch, bracketed by hipEvents on the context's

@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
     Stamp *st; CK(hipMalloc(&st, sizeof(Stamp) * C * N));
     hipStream_t s; CK(hipStreamCreate(&s));
     const int blocks1 = C * (N / kWgRows), blocks2 = C * (N / kWgRows); const int thr1 = plan_wg_threads(N), thr2 = plan_wg_threads(N);
-    DebugArgs dbg{st, 0, 0};
+    DebugArgs dbg{st, 0};
     const int iters = argc > 2 ? atoi(argv[2]) : 30;
     for (int i = 0; i < 600; ++i) { hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg); hipLaunchKernelGGL((k_pass2<N, false, 0>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }
     CK(hipStreamSynchronize(s));
@@ -58,9 +58,6 @@ int main(int argc, char **argv) {
 #define RUN2(VAR) printf("pass2 var %2d : %8.2f us\n", VAR, time_it([&] { hipLaunchKernelGGL((k_pass2<N, false, VAR>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }, iters, s));
     RUN1(0) RUN1(1) RUN1(2) RUN1(3) RUN1(4) RUN1(5) RUN1(6) RUN1(7)
     RUN2(0) RUN2(1) RUN2(2) RUN2(3) RUN2(4) RUN2(5) RUN2(6) RUN2(7)
-    for (int groups = 2; groups <= 8; groups *= 2) for (int shift : {3, 4, 8}) for (int unit : {2, 4, 8, 12}) { DebugArgs d2{st, 0, unit | (shift << 8) | (groups << 16)};
-        if (groups * unit > 48) continue;
-        printf("pass1 stagger groups %d shift %d unit %2d : %8.2f us\n", groups, shift, unit, time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0>), dim3(blocks1), dim3(thr1), 0, s, buf, args, d2); }, iters, s)); }
 #define RUNP1(AT, AH) printf("pass1 aux T=%d H=%d : %8.2f us\n", AT, AH, time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0, AT, AH>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg); }, iters, s));
 #define RUNP2(AT, AO) printf("pass2 aux T=%d O=%d : %8.2f us\n", AT, AO, time_it([&] { hipLaunchKernelGGL((k_pass2<N, false, 0, AT, AO>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }, iters, s));
 #define TICK(A1T, A1H, A2T, A2O) printf("tick aux p1(T=%d H=%d) p2(T=%d O=%d) : %8.2f us\n", A1T, A1H, A2T, A2O, time_it([&] { hipLaunchKernelGGL((k_pass1<N, 0, A1T, A1H>), dim3(blocks1), dim3(thr1), 0, s, buf, args, dbg); hipLaunchKernelGGL((k_pass2<N, false, 0, A2T, A2O>), dim3(blocks2), dim3(thr2), 0, s, buf, args, dbg); }, iters, s));
