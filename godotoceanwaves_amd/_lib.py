@@ -9,6 +9,7 @@ OW_MAX_CASCADES = 8
 OW_FLAG_DEBUG_F32 = 1
 OW_FLAG_KERNELS_STANDARD = 2
 OW_FLAG_KERNELS_LAYER_PARALLEL = 4
+OW_FLAG_KERNELS_COMPACT = 8
 OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
 
 

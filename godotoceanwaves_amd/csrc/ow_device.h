@@ -705,6 +705,65 @@ struct Pass1 {
         }
     }
 
+    // ---- compact intermediate: three layers instead of four (tests/test_compact_math.py holds the algebra) ----
+    // Off the two Nyquist lines all eight fields of spectrum_modulate.glsl:72-82 are real and three of them are
+    // i*ky times three others (dhx_dx = i ky hx, dhy_dx = i ky hy, dhz_dx = i ky hz), ky being the axis PASS 2
+    // transforms: pass 2 can form them itself from what it loads.  Only five real fields cross the intermediate:
+    //   C0 = hx + i hy = i (1 + uy) h      C1 = hz = i ux h  (alone)      C2 = dhy_dz + i dhz_dz = i kx (1 - ux) h
+    // On texel column id.x = 0 (lane 0, slot kColSlot; kx = -N/2 dkx is not mirrored there) the
+    // reference's layers are not Hermitian-consistent; what they leak is reproduced in closed form:
+    //   C1 <- 0,   C2 <- ux (ky - i kx) h,   and pass 2 adds  column_term = (kx + i ux) h  to its derived  i ky C0.
+    // Texel row id.y = 0 is carried separately as three extra transforms (row0_input).
+    static constexpr int kCompactLayers = 3, kColSlot = 8;  // rot(kColSlot) == 0
+    template <int L, class Hook = NoHook>
+    static OW_DEV void layer_input_c(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx, Hook after_group = Hook()) {
+        const float kx0 = (float)(t - N / 2) * dkx;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const cplx ih = cmuli(h[j]);
+            const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
+            if (L == 0) d[j] = cscale(ih, 1.0f + ky * ik[j]);
+            if (L == 1) d[j] = cscale(ih, ux);
+            if (L == 2) d[j] = cscale(ih, __builtin_fmaf(-kx, ux, kx));
+            if (j == kColSlot && L > 0) {
+                const cplx line = (L == 1) ? cplx{0.0f, 0.0f} : cadd(cscale(h[j], ux * ky), cscale(ih, -(ux * kx)));
+                d[j] = cplx{t == 0 ? line.x : d[j].x, t == 0 ? line.y : d[j].y};
+            }
+            opaque_inplace(d[j]);
+            if (j % 4 == 3) {
+                OW_SCHED_FENCE();
+                after_group(j / 4);
+                OW_SCHED_FENCE();
+            }
+        }
+    }
+    // (kx + i ux) h at the lane's texel of slot kColSlot: meaningful in lane 0 (texel x = 0) only
+    static OW_DEV cplx column_term(const cplx *h, const float *ik, int t, float dkx) {
+        const float kx = kx_of(kColSlot, (float)(t - N / 2) * dkx, dkx), ux = kx * ik[kColSlot];
+        return cadd(cscale(h[kColSlot], kx), cscale(cmuli(h[kColSlot]), ux));
+    }
+    // Texel row id.y = 0 (ky = -N/2 dky): the pass-2 inputs at ky-index 0 are the row transforms of
+    //   Q1 = -ky uy h  (-> dhx_dx + i dhy_dx)     Q2 = (i ux - ky) h  (-> hz + i dhz_dx)
+    //   Q3 = (i kx (1 - ux) + ky ux) h  (-> dhy_dz + i dhz_dz);   Q0 = C0 is the row's ordinary layer 0.
+    // The corner texel (0, 0) mirrors onto itself and has its own forms.
+    template <int Q>
+    static OW_DEV void row0_input(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx) {
+        const float kx0 = (float)(t - N / 2) * dkx;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const cplx ih = cmuli(h[j]);
+            const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j], uy = ky * ik[j];
+            const bool corner = (j == kColSlot) && (t == 0);
+            float a = 0.0f, b = 0.0f;  // d = a h + b (i h)
+            if (Q == 1) { a = corner ? kx - ky * uy : -(ky * uy); b = corner ? ux : 0.0f; }
+            if (Q == 2) { a = -ky; b = corner ? -(ky * ux) : ux; }
+            if (Q == 3) { a = corner ? 0.0f : ky * ux; b = corner ? -(kx * ux) : __builtin_fmaf(-kx, ux, kx); }
+            d[j] = cadd(cscale(h[j], a), cscale(ih, b));
+            opaque_inplace(d[j]);
+            if (j % 4 == 3) OW_SCHED_FENCE();
+        }
+    }
+
     // Transposed store of one layer.  stage_write: every lane puts its own row's results, x'-ordered, into
     // its row region (8 B per x', linear).  After a workgroup (LDS) barrier, stage_store: thread tau of the
     // block takes (row q = tau % 8, x' = tau / 8 + T*k), so that 8 consecutive lanes write the 8 consecutive
@@ -844,6 +903,94 @@ struct Pass2 {
             }
         }
     }
+    // ---- compact intermediate (see Pass1::layer_input_c): four transforms from three loaded layers ----
+    //   F1 = row transform of  i ky C0 + (-1)^x' P   -> (dhx_dx, dhy_dx)       F3 = of C2  -> (dhy_dz, dhz_dz)
+    //   F2 = of (1 - ky) C1  -> (hz, dhz_dx)   [C1 is Hermitian along ky]        F0 = of C0  -> (hx, hy)
+    // with element ky-index 0 (lane 0, slot kRow0Slot) of F1..F3 replaced by the separately transformed texel row 0.
+    static constexpr int kRow0Slot = 8;  // rot(kRow0Slot) == 0
+    static OW_DEV float ky_of(int j, int t, float dky) { return (float)(t + T * (rot(j) - 8)) * dky; }
+    // P(ky): one complex per map row y, stored in this kernel's lane order (a lane's 16 values = 128 contiguous bytes)
+    OW_HD static constexpr uint32_t pcol_index(int y) { return (uint32_t)(y % T) * 16u + (uint32_t)(y / T); }
+    // d[j] = i ky d[j] + sign * P[y_j]
+    static OW_DEV void derive_dx(cplx *d, int t, int xp, float dky, GBuf pcol_c) {
+        const float s = (xp & 1) ? -1.0f : 1.0f;
+        cplx p[P];  // natural order o = y / T
+#pragma unroll
+        for (int i = 0; i < P / 2; ++i) {
+            const f32x4 v = gload16(pcol_c, (uint32_t)t * 128u, 16u * (uint32_t)i);
+            p[2 * i] = cplx{v.x, v.y};
+            p[2 * i + 1] = cplx{v.z, v.w};
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const float ky = ky_of(j, t, dky);
+            const cplx pv = p[rot(j)];
+            d[j] = cplx{__builtin_fmaf(-ky, d[j].y, s * pv.x), __builtin_fmaf(ky, d[j].x, s * pv.y)};
+        }
+    }
+    static OW_DEV void scale_hz(cplx *d, int t, float dky) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) d[j] = cscale(d[j], 1.0f - ky_of(j, t, dky));
+    }
+    static OW_DEV void put_row0(cplx *d, int t, cplx r) {
+        d[kRow0Slot] = cplx{t == 0 ? r.x : d[kRow0Slot].x, t == 0 ? r.y : d[kRow0Slot].y};
+    }
+    // F1 done: dhx_dx (kept in FP32 for the Jacobian) and gx; gxdx[o] = halves (gx | dhx_dx << 16) for the normal map
+    template <bool F32>
+    static OW_DEV void after_f1(const cplx *f1, float *dhx_dx, uint32_t *gxdx, uint32_t tex, GBuf f32_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            dhx_dx[o] = f1[sl].x;
+            const float gx = f1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o]));
+            gxdx[o] = (uint32_t)f2h(gx) | ((uint32_t)f2h(dhx_dx[o]) << 16);
+            if (F32) {
+                f32_put(f32_c, tex, o, 3, gx);
+                f32_put(f32_c, tex, o, 5, dhx_dx[o]);
+            }
+        }
+    }
+    // F3 done: jpart = (1 + dhx_dx)(1 + dhz_dz) replaces dhx_dx; gy halves, two per word
+    template <bool F32>
+    static OW_DEV void after_f3(const cplx *f3, float *jpart, uint32_t *gy_pk, uint32_t tex, GBuf f32_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            const float dhy_dz = f3[sl].x, dhz_dz = f3[sl].y;
+            jpart[o] = (1.0f + jpart[o]) * (1.0f + dhz_dz);
+            const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
+            const uint32_t gh = f2h(gy);
+            gy_pk[o / 2] = (o & 1) ? (gy_pk[o / 2] | (gh << 16)) : gh;
+            if (F32) f32_put(f32_c, tex, o, 4, gy);
+        }
+    }
+    // F2 done: Jacobian -> foam recurrence (fft_unpack.glsl:55-64), normal map store; hz stays for the displacement store
+    template <bool F32, int AUX>
+    static OW_DEV void after_f2(const cplx *f2, const float *jpart, const uint32_t *gxdx, const uint32_t *gy_pk, uint32_t *foam_pk,
+                                float *hz, uint32_t tex, const CascadeFrame &cf, GBuf norm_c, GBuf f32_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            hz[o] = f2[sl].x;
+            const float dhz_dx = f2[sl].y;
+            const float jac = jpart[o] - dhz_dx * dhz_dx;
+            const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
+            float foam = h2f((uint16_t)((foam_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu));
+            foam = mul_rn(foam, cf.foam_decay);
+            foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
+            foam = fminf(fmaxf(foam, 0.0f), 1.0f);
+            const uint32_t foam_h = f2h(foam);
+            foam_pk[o / 2] = (o & 1) ? ((foam_pk[o / 2] & 0xFFFFu) | (foam_h << 16)) : ((foam_pk[o / 2] & 0xFFFF0000u) | foam_h);
+            const uint16_t gy_h = (uint16_t)((gy_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
+            gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u,
+                          u16x4{(uint16_t)(gxdx[o] & 0xFFFFu), gy_h, (uint16_t)(gxdx[o] >> 16), (uint16_t)foam_h});
+            if (F32) {
+                f32_put(f32_c, tex, o, 6, foam);
+                f32_put(f32_c, tex, o, 7, jac);
+            }
+        }
+    }
+
     // The whole of fft_unpack.glsl:44-67 for ONE texel whose four layer values are at hand (layer-parallel pass 2).
     // foam_prev / foam_new: FP16 bits of the recurrent state.  o = the lane's output ordinal (texel t + T*o).
     template <bool F32, int AUX>

@@ -13,38 +13,69 @@ static void launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const LaunchT
     else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
 }
 
+// family the runtime picks for batches too large for the layer-parallel kernels, where the compact kernels exist
+constexpr int kAutoLargeFamily = 1;
+
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
-// Small batches take the layer-parallel kernels: up to ~1024 waves of row work the standard kernels cannot fill
-// the chip and run at one wave's serial latency.  mode: 0 = choose by size, 1 = standard, 2 = layer-parallel.
+// Kernel family of a batch.  mode: 0 = choose by size, 1 = standard (four-layer intermediate in the reference's packing),
+// 2 = layer-parallel, 3 = compact (three-layer intermediate).  Small batches take the layer-parallel kernels: up to
+// ~1024 waves of row work the standard kernels cannot fill the chip and run at one wave's serial latency.
 template <int N>
-static bool use_lp(int slots, int mode) {
-    if (mode == 1) return false;
-    if (mode == 2) return true;
-    return (long)slots * N * plan_T(N) / 64 <= 1024;  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
+static int family(int slots, int mode) {
+    constexpr bool has_compact = plan_T(N) >= 64;
+    if (mode == 1 || mode == 2) return mode;
+    if (mode == 3) return has_compact ? 3 : 1;
+    if ((long)slots * N * plan_T(N) / 64 <= 1024) return 2;  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
+    return has_compact ? kAutoLargeFamily : 1;
 }
 template <int N>
 static hipError_t launch1(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
-    const int blocks = slots * (N / kWgRows);
-    if (use_lp<N>(slots, mode)) {
+    const int blocks = slots * (N / kWgRows), fam = family<N>(slots, mode);
+    if (fam == 2) {
         launch(k_pass1_lp<N>, dim3(blocks, kLayers), dim3(plan_wg_threads(N)), s, lt, buf, args);
         return hipGetLastError();
+    }
+    if constexpr (plan_T(N) >= 64) {
+        if (fam == 3) {
+            launch(k_pass1c<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            return hipGetLastError();
+        }
     }
     launch(k_pass1<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     return hipGetLastError();
 }
 template <int N>
 static hipError_t launch2(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
-    if (use_lp<N>(slots, mode)) {
+    const int fam = family<N>(slots, mode);
+    if (fam == 2) {
         const int lp_blocks = slots * (N / plan_lp_rows(N));
         if (buf.f32) launch(k_pass2_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
         else launch(k_pass2_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
         return hipGetLastError();
     }
     const int blocks = slots * (N / kWgRows);
+    if constexpr (plan_T(N) >= 64) {
+        if (fam == 3) {
+            if (buf.f32) launch(k_pass2c<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            else launch(k_pass2c<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            return hipGetLastError();
+        }
+    }
     if (buf.f32) launch(k_pass2<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     else launch(k_pass2<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     return hipGetLastError();
+}
+
+int kernel_family(int n, int slots, int mode) {
+    switch (n) {
+        case 128: return family<128>(slots, mode);
+        case 256: return family<256>(slots, mode);
+        case 512: return family<512>(slots, mode);
+        case 1024: return family<1024>(slots, mode);
+        case 2048: return family<2048>(slots, mode);
+    }
+    return 0;
 }
 
 hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {

@@ -15,6 +15,8 @@
 // Workgroup barriers are LDS-only (lds_barrier): they never wait for global loads or stores, so the stores
 // of one layer drain underneath the next layer's butterflies.
 #pragma once
+#include <type_traits>
+
 #include "ow_kernels.h"
 
 #ifndef OW_P1_WAVES
@@ -369,6 +371,161 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     }
 }
 
+
+// ===================================================================================================
+// COMPACT-INTERMEDIATE variants of the two standard kernels (N >= 1024: a wave carries whole rows).  Three packed
+// layers cross T instead of four (24 instead of 32 B/texel each way): see Pass1::layer_input_c / Pass2::derive_dx in
+// ow_device.h and tests/test_compact_math.py for the algebra.  Same structure as k_pass1 / k_pass2 otherwise.
+// ===================================================================================================
+template <int N, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP, LC = Pass1<N>::kCompactLayers;
+    static_assert(Tn >= 64, "a wave must not mix rows");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int rw = __builtin_amdgcn_readfirstlane(tau / Tn), t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
+
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    const int y = row0 + rw;
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+
+    cplx h[P];
+    Pass1<N>::template load_modulate<AUX_H>(h, t, y, h0_c, om_c, cf.time);
+    load_twiddles<N>(tw_lds, buf.tw);
+    const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    const float ky = (float)(y - N / 2) * dky;
+    float ik[P];
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
+
+    if (y == 0) {  // wave-uniform, one row per cascade: the three extra transforms of texel row 0, straight to the side buffer
+        auto extra = [&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            cplx d[P];
+            Pass1<N>::template row0_input<Q>(d, h, ik, t, ky, dkx);
+            row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
+            rs.sync();  // the row region is free again before the next transform writes into it
+#pragma unroll
+            for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)Q * 8u, d[OutMap<N>::slot_of(o)]);
+        };
+        extra(std::integral_constant<int, 1>{});
+        extra(std::integral_constant<int, 2>{});
+        extra(std::integral_constant<int, 3>{});
+    }
+
+#pragma unroll
+    for (int L = 0; L < LC; ++L) {
+        cplx d[P];
+        OW_SCHED_FENCE();
+        {
+            const float kyo = opaque(ky), dkxo = opaque(dkx);
+            const int to = opaque(t);
+#pragma unroll
+            for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
+            auto drain = [&](int g) {
+                if (L > 0) Pass1<N>::template stage_store_chunk<AUX_T>(tau, L - 1, row0, rows_lds, T_c, g);
+            };
+            if (L == 0) Pass1<N>::template layer_input_c<0>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 1) Pass1<N>::template layer_input_c<1>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 2) Pass1<N>::template layer_input_c<2>(d, h, ik, to, kyo, dkxo, drain);
+        }
+        OW_SCHED_FENCE();
+        if (L > 0) row_ifft<N, true>(d, t, lds_row, tw_lds, rs);
+        else row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
+        rs.sync();
+        Pass1<N>::stage_write(d, t, lds_row);
+        lds_barrier();
+        if (L == LC - 1) Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+    }
+}
+
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP;
+    static_assert(Tn >= 64, "a wave must not mix rows");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int rw = __builtin_amdgcn_readfirstlane(tau / Tn), t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
+
+    int slot, row0;
+    p2_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    const int xp = row0 + rw;
+    const uint32_t tex = (uint32_t)(xp * N + t);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
+    const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
+    const float dky = (2.0f * kPi) / cf.tile_y;
+    // texel row 0's three transforms at this x' (ky-index 0 of F1..F3)
+    const cplx r1 = gload8(rrow_c, (uint32_t)xp * 32u, 8u), r2 = gload8(rrow_c, (uint32_t)xp * 32u, 16u), r3 = gload8(rrow_c, (uint32_t)xp * 32u, 24u);
+
+    float jpart[P];   // dhx_dx after F1, (1 + dhx_dx)(1 + dhz_dz) after F3
+    uint32_t gxdx[P], gy_pk[P / 2];
+    {
+        cplx f1[P];
+        OW_SCHED_FENCE();
+        Pass2<N>::template load_layer<AUX_T>(f1, t, xp, 0, T_c);
+        load_twiddles<N>(tw_lds, buf.tw);
+        Pass2<N>::derive_dx(f1, t, xp, dky, pcol_c);
+        Pass2<N>::put_row0(f1, t, r1);
+        row_ifft<N>(f1, t, lds_row, tw_lds, rs);
+        Pass2<N>::template after_f1<F32>(f1, jpart, gxdx, tex, f32_c);
+    }
+    {
+        cplx f3[P];
+        OW_SCHED_FENCE();
+        Pass2<N>::template load_layer<AUX_T>(f3, t, xp, 2, T_c);
+        Pass2<N>::put_row0(f3, t, r3);
+        row_ifft<N>(f3, t, lds_row, tw_lds, rs);
+        Pass2<N>::template after_f3<F32>(f3, jpart, gy_pk, tex, f32_c);
+    }
+    float hz[P];
+    {
+        cplx f2[P];
+        uint32_t foam_pk[P / 2];
+        OW_SCHED_FENCE();
+        Pass2<N>::template load_layer<AUX_T>(f2, t, xp, 1, T_c);
+        Pass2<N>::load_foam(foam_pk, t, xp, foam_c);
+        Pass2<N>::scale_hz(f2, t, dky);
+        Pass2<N>::put_row0(f2, t, r2);
+        row_ifft<N>(f2, t, lds_row, tw_lds, rs);
+        Pass2<N>::template after_f2<F32, AUX_O>(f2, jpart, gxdx, gy_pk, foam_pk, hz, tex, cf, norm_c, f32_c);
+        Pass2<N>::store_foam(foam_pk, t, xp, foam_c);
+    }
+    {
+        cplx f0[P];
+        OW_SCHED_FENCE();
+        Pass2<N>::template load_layer<AUX_T>(f0, t, xp, 0, T_c);
+        row_ifft<N>(f0, t, lds_row, tw_lds, rs);
+        Pass2<N>::template after_layer0<F32, AUX_O>(f0, hz, t, xp, tex, disp_c, f32_c);
+    }
+}
 
 // ===================================================================================================
 // LAYER-PARALLEL variants for small batches (up to ~1024 waves of row work: one cascade of 1024^2, four of 512^2, anything at

@@ -17,6 +17,9 @@ struct DeviceBuffers {
     uint16_t *foam; // [layers][N x'][N/16 t][16 o] FP16: private copy of normal.a in pass-2 lane order (Pass2::foam_index)
     float *f32;     // [layers][N][N][8] or nullptr
     const cplx *tw; // twiddle table (plan_tw_total(N) entries)
+    // compact-intermediate side buffers (Pass1::layer_input_c), scratch of one batch like T:
+    cplx *pcol;     // [launch slot][N]     P(ky) of texel column id.x = 0, in pass-2 lane order (Pass2::pcol_index)
+    cplx *rrow;     // [launch slot][N x'][4] row transforms Q1..Q3 of texel row id.y = 0 (entry 0 unused)
 };
 
 // optional events bound to a launch's own dispatch packet (begin / end of the kernel itself)
@@ -40,9 +43,10 @@ hipError_t launch_sample_surface(int n, int cascades, const DeviceBuffers &buf, 
                                  const SurfaceScales &scales, SurfaceSample *out_dev, hipStream_t s);
 
 bool supported_map_size(int n);
+int kernel_family(int n, int slots, int mode);  // 1 standard, 2 layer-parallel, 3 compact: what launch_pass1/2 will use
 hipError_t launch_spectrum(int n, int cascade, const SpectrumPC &pc, const DeviceBuffers &buf, hipStream_t s);
 hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,
-                        const LaunchTiming &lt = LaunchTiming{});  // mode: 0 auto, 1 standard, 2 layer-parallel
+                        const LaunchTiming &lt = LaunchTiming{});  // mode: 0 auto, 1 standard, 2 layer-parallel, 3 compact
 hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,
                         const LaunchTiming &lt = LaunchTiming{});
 

@@ -49,7 +49,8 @@ constexpr double kHostG = 9.81;  // wave_generator.gd:5
 struct ow_context {
     int n = 0, cascades = 0, layers = 0, device = 0;
     float depth = 20.0f;
-    int kernel_mode = 0;  // 0 = by batch size, 1 = standard kernels, 2 = layer-parallel kernels (OW_FLAG_KERNELS_*)
+    int kernel_mode = 0;  // 0 = by batch size, 1 = standard, 2 = layer-parallel, 3 = compact-intermediate kernels (OW_FLAG_KERNELS_*)
+    int last_family = 0;  // kernel family of the most recent batch
     hipStream_t stream = nullptr;
     bool own_stream = false, own_disp = false, own_norm = false;
     ow::DeviceBuffers buf{};
@@ -166,6 +167,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         for (int i = 0; i < nb; ++i) part.c[i] = args.c[b0 + i];
         c->last_args = part;
         c->last_count = nb;
+        c->last_family = ow::kernel_family(c->n, nb, c->kernel_mode);
         for (int &sl : c->slot_of) sl = -1;
         for (int i = 0; i < nb; ++i) c->slot_of[part.c[i].cascade] = i;
         hipEvent_t *ev = nullptr;
@@ -244,7 +246,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->layers = cfg->num_cascades < 2 ? 2 : cfg->num_cascades;  // init_gpu(maxi(2, n)), water.gd:91
     c->device = dev;
     c->depth = cfg->depth > 0.0f ? cfg->depth : 20.0f;  // DEPTH, wave_generator.gd:6
-    c->kernel_mode = (cfg->flags & OW_FLAG_KERNELS_STANDARD) ? 1 : ((cfg->flags & OW_FLAG_KERNELS_LAYER_PARALLEL) ? 2 : 0);
+    c->kernel_mode = (cfg->flags & OW_FLAG_KERNELS_STANDARD) ? 1 : (cfg->flags & OW_FLAG_KERNELS_LAYER_PARALLEL) ? 2 : (cfg->flags & OW_FLAG_KERNELS_COMPACT) ? 3 : 0;
 
     auto bail = [&](ow_status st) {
         ow_destroy(c);
@@ -280,6 +282,11 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     }
     OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
     if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
+    {   // side buffers of the compact intermediate, one batch worth like T
+        const size_t slots = (size_t)std::min((int)L, batch_size(c));
+        OW_ALLOC(c->buf.pcol, slots * c->n * sizeof(ow::cplx));
+        OW_ALLOC(c->buf.rrow, slots * c->n * 4 * sizeof(ow::cplx));
+    }
     std::vector<ow::cplx> tw;
     ow::make_twiddles(c->n, tw);
     OW_ALLOC(c->tw_dev, tw.size() * sizeof(ow::cplx));
@@ -310,6 +317,8 @@ void ow_destroy(ow_context *c) {
     if (c->own_norm) (void)hipFree(c->buf.norm);
     (void)hipFree(c->buf.foam);
     (void)hipFree(c->buf.f32);
+    (void)hipFree(c->buf.pcol);
+    (void)hipFree(c->buf.rrow);
     (void)hipFree(c->tw_dev);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipFree(c->snap_dev);
@@ -549,6 +558,9 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     std::vector<ow::cplx> t(pl * ow::kLayers);
     if (c->slot_of[cascade] < 0)
         return fail(OW_ERR_STATE, "cascade %d was not part of the most recent batch: its intermediate has been overwritten", cascade);
+    if (c->last_family == 3)
+        return fail(OW_ERR_STATE, "the most recent batch used the compact (three-layer) intermediate, which has no counterpart in the "
+                                  "reference's fft_buffer: create the context with OW_FLAG_KERNELS_STANDARD to inspect it");
     OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + (size_t)c->slot_of[cascade] * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
     OW_HIP(hipStreamSynchronize(c->stream));
     // device layout T[layer][y/16][x'][y%16]  ->  reference half-0-after-transpose layout [layer][row = x'][col = y].

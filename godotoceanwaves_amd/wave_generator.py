@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, ow_cascade_params,
+from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_COMPACT, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, ow_cascade_params,
                    ow_config)
 
 G = 9.81       # wave_generator.gd:5
@@ -124,7 +124,8 @@ class WaveGenerator:
         cfg = ow_config(map_size=int(self.map_size), num_cascades=int(num_cascades), device_id=self.device_id,
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
                         normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) |
-                        {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL}[self.kernels])
+                        {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL,
+                               "compact": OW_FLAG_KERNELS_COMPACT}[self.kernels])
         ctx = C.c_void_p()
         _lib.check(self._lib.ow_create(C.byref(cfg), C.byref(ctx)))
         self.context = ctx

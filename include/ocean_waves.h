@@ -79,6 +79,9 @@ typedef struct ow_config {
  * sequence) otherwise.  These two flags pin the choice (tests, measurements). */
 #define OW_FLAG_KERNELS_STANDARD 2u
 #define OW_FLAG_KERNELS_LAYER_PARALLEL 4u
+/* Compact-intermediate kernels (map_size >= 1024): three packed layers cross the intermediate instead of the
+ * reference's four; ow_get_intermediate is not available for batches that used them. */
+#define OW_FLAG_KERNELS_COMPACT 8u
 
 typedef struct ow_context ow_context;
 

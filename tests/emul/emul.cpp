@@ -158,6 +158,101 @@ void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, u
     }
 }
 
+// the same frame through the compact (three-layer) intermediate: mirrors k_pass1c / k_pass2c
+template <int N>
+void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
+    constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
+    const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    const uint32_t plane = (uint32_t)N * N;
+    const GBuf h0_c = make_gbuf(h0a, plane * 8u), om_c = make_gbuf(omega, plane * 4u), T_c = make_gbuf(Tbuf, t_cascade_bytes(N));
+    const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), foam_c = make_gbuf(foam, plane * 2u), f32_c = make_gbuf(f32, plane * 32u);
+    std::vector<cplx> pcol(N), rrow((size_t)N * 4);
+    const GBuf pcol_c = make_gbuf(pcol.data(), (uint32_t)N * 8u), rrow_c = make_gbuf(rrow.data(), (uint32_t)N * 32u);
+    Block<N, NT> w;
+    {   // ---- pass 1 ----
+        static cplx h[NT][P], d[NT][P];
+        static float ik[NT][P];
+        for (int row0 = 0; row0 < N; row0 += kWgRows) {
+            for (int l = 0; l < NT; ++l) Pass1<N>::load_modulate(h[l], l % Tn, row0 + l / Tn, h0_c, om_c, cf.time);
+            for (int l = 0; l < NT; ++l) Pass1<N>::wave_numbers(ik[l], l % Tn, (float)(row0 + l / Tn - N / 2) * dky, dkx);
+            for (int l = 0; l < NT; ++l)
+                if (l % Tn == 0) gstore8(pcol_c, Pass2<N>::pcol_index(row0 + l / Tn) * 8u, 0u, Pass1<N>::column_term(h[l], ik[l], 0, dkx));
+            if (row0 == 0) {  // texel row 0: three extra transforms, results to the side buffer (only the lanes of row 0 matter)
+                for (int Q = 1; Q <= 3; ++Q) {
+                    for (int l = 0; l < NT; ++l) {
+                        const float ky = (float)(l / Tn - N / 2) * dky;
+                        if (Q == 1) Pass1<N>::template row0_input<1>(d[l], h[l], ik[l], l % Tn, ky, dkx);
+                        if (Q == 2) Pass1<N>::template row0_input<2>(d[l], h[l], ik[l], l % Tn, ky, dkx);
+                        if (Q == 3) Pass1<N>::template row0_input<3>(d[l], h[l], ik[l], l % Tn, ky, dkx);
+                    }
+                    w.row_ifft(d);
+                    for (int l = 0; l < Tn; ++l)
+                        for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(l + Tn * o) * 32u, (uint32_t)Q * 8u, d[l][OutMap<N>::slot_of(o)]);
+                }
+            }
+            for (int L = 0; L < Pass1<N>::kCompactLayers; ++L) {
+                for (int l = 0; l < NT; ++l) {
+                    const int y = row0 + l / Tn, t = l % Tn;
+                    const float ky = (float)(y - N / 2) * dky;
+                    if (L == 0) Pass1<N>::template layer_input_c<0>(d[l], h[l], ik[l], t, ky, dkx);
+                    if (L == 1) Pass1<N>::template layer_input_c<1>(d[l], h[l], ik[l], t, ky, dkx);
+                    if (L == 2) Pass1<N>::template layer_input_c<2>(d[l], h[l], ik[l], t, ky, dkx);
+                }
+                w.row_ifft(d);
+                for (int l = 0; l < NT; ++l) Pass1<N>::stage_write(d[l], l % Tn, w.row(l));
+                for (int l = 0; l < NT; ++l) Pass1<N>::template stage_store<0>(l, L, row0, w.lds.data(), T_c);
+            }
+        }
+    }
+    {   // ---- pass 2: F1, F3, F2, F0 ----
+        static cplx f[NT][P];
+        static float jpart[NT][P], hz[NT][P];
+        static uint32_t gxdx[NT][P], gy_pk[NT][P / 2], foam_pk[NT][P / 2];
+        for (int row0 = 0; row0 < N; row0 += kWgRows) {
+            auto xp_of = [&](int l) { return row0 + l / Tn; };
+            auto tex_of = [&](int l) { return (uint32_t)(xp_of(l) * N + l % Tn); };
+            auto r_of = [&](int l, int q) { return gload8(rrow_c, (uint32_t)xp_of(l) * 32u, (uint32_t)q * 8u); };
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 0, T_c);
+                Pass2<N>::derive_dx(f[l], l % Tn, xp_of(l), dky, pcol_c);
+                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 1));
+            }
+            w.row_ifft(f);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_f1<true>(f[l], jpart[l], gxdx[l], tex_of(l), f32_c);
+                else Pass2<N>::template after_f1<false>(f[l], jpart[l], gxdx[l], tex_of(l), f32_c);
+            }
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 2, T_c);
+                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 3));
+            }
+            w.row_ifft(f);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_f3<true>(f[l], jpart[l], gy_pk[l], tex_of(l), f32_c);
+                else Pass2<N>::template after_f3<false>(f[l], jpart[l], gy_pk[l], tex_of(l), f32_c);
+            }
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 1, T_c);
+                Pass2<N>::scale_hz(f[l], l % Tn, dky);
+                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 2));
+                Pass2<N>::load_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
+            }
+            w.row_ifft(f);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_f2<true, 0>(f[l], jpart[l], gxdx[l], gy_pk[l], foam_pk[l], hz[l], tex_of(l), cf, norm_c, f32_c);
+                else Pass2<N>::template after_f2<false, 0>(f[l], jpart[l], gxdx[l], gy_pk[l], foam_pk[l], hz[l], tex_of(l), cf, norm_c, f32_c);
+                Pass2<N>::store_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
+            }
+            for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 0, T_c);
+            w.row_ifft(f);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_layer0<true, 0>(f[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
+                else Pass2<N>::template after_layer0<false, 0>(f[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +292,17 @@ int emul_frame(int n, const float *h0a, const float *omega, const CascadeFrame *
         case 512: frame<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 1024: frame<1024>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 2048: frame<2048>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+    }
+    return 1;
+}
+
+int emul_frame_compact(int n, const float *h0a, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
+                       uint16_t *norm, uint16_t *foam, float *f32) {
+    switch (n) {
+        case 128: frame_compact<128>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 256: frame_compact<256>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 512: frame_compact<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+        case 1024: frame_compact<1024>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
     }
     return 1;
 }

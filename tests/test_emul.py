@@ -39,6 +39,7 @@ def emul():
     E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
     E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p, f32p]
     E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
+    E.emul_frame_compact.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
     return E
 
@@ -65,8 +66,12 @@ def test_row_ifft_is_unnormalised_inverse_dft(emul, n):
     assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 5e-7
 
 
+@pytest.mark.parametrize("intermediate", ["reference_layout", "compact"])
 @pytest.mark.parametrize("n,ci", [(128, 0), (256, 2), (512, 1)])
-def test_emulated_kernels_match_oracle(emul, n, ci):
+def test_emulated_kernels_match_oracle(emul, n, ci, intermediate):
+    """both kernel families: the four-layer intermediate of the reference and the compact three-layer one
+    (Pass1::layer_input_c, tests/test_compact_math.py)"""
+    frame_fn = emul.emul_frame if intermediate == "reference_layout" else emul.emul_frame_compact
     p = cascade_preset(ci)
     pc = H.spectrum_pc(p)
     epc = PC(p["spectrum_seed"][0], p["spectrum_seed"][1], p["tile_length"][0], p["tile_length"][1], pc.alpha, pc.peak_frequency,
@@ -87,7 +92,7 @@ def test_emulated_kernels_match_oracle(emul, n, ci):
                 np.exp(-np.float32(P.foam_decay_rate), dtype=np.float32), 0, 0)
         T = np.zeros((n * n * 4 * 2,), np.float32)
         disp, f32 = np.zeros((n, n, 4), np.uint16), np.zeros((n, n, 8), np.float32)
-        assert emul.emul_frame(n, h0a, om, C.byref(cf), T, disp, norm, foam, f32) == 0
+        assert frame_fn(n, h0a, om, C.byref(cf), T, disp, norm, foam, f32) == 0
         ref = g.f32(0)
         for c, name in enumerate(H.CHANNELS):
             if name == "foam":

@@ -229,3 +229,32 @@ def test_invalid_arguments_are_errors():
         gen.get_maps_f32(0)                                             # context created without DEBUG_F32
     with pytest.raises(_lib.OceanWavesError):
         gen.get_maps(5)
+
+
+@pytest.mark.parametrize("n,ids", [(1024, [0, 2]), (1024, [1, 3, 4, 5, 6]), (2048, [2])])
+def test_compact_intermediate_kernels_match_oracle(n, ids):
+    """The three-layer intermediate (Pass1::layer_input_c, tests/test_compact_math.py) against the oracle: same tolerances as
+    the reference-layout kernels, including the Nyquist row / column the closed forms reproduce; the debug view of the
+    intermediate is refused for such batches."""
+    gen, params = make_gen(n, ids, kernels="compact")
+    og = H.oracle_generator(n, ids)
+    for frame in range(3):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    for i in range(len(ids)):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < 1e-5, (i, name, H.relmax(f32[..., c], ref[..., c]))
+                # the two Nyquist lines on their own (row 0 and column 0 of the map carry no special role in the OUTPUT;
+                # the lines live in the spectrum -- so compare the worst texel row / column as well)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
+        assert H.fp16_close(disp, og.displacement(i)) <= 1.0
+        assert H.fp16_close(norm[..., :3], og.normal(i)[..., :3]) <= 1.0
+    with pytest.raises(_lib.OceanWavesError) as e:
+        gen.get_intermediate(0)
+    assert e.value.status == _lib.OW_ERR_STATE
