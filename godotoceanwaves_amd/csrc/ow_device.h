@@ -709,7 +709,9 @@ struct Pass1 {
     // Off the two Nyquist lines all eight fields of spectrum_modulate.glsl:72-82 are real and three of them are
     // i*ky times three others (dhx_dx = i ky hx, dhy_dx = i ky hy, dhz_dx = i ky hz), ky being the axis PASS 2
     // transforms: pass 2 can form them itself from what it loads.  Only five real fields cross the intermediate:
-    //   C0 = hx + i hy = i (1 + uy) h      C1 = hz = i ux h  (alone)      C2 = dhy_dz + i dhz_dz = i kx (1 - ux) h
+    //   C0 = hx + i hy = i (1 + uy) h      C1 = (1 - ky) hz = (1 - ky) i ux h      C2 = dhy_dz + i dhz_dz = i kx (1 - ux) h
+    // (hz travels alone: its spectrum is Hermitian along ky, so the transform of (1 - ky) hz = hz + i (i ky hz) is
+    // hz + i dhz_dx, two real fields again; the factor is uniform over a pass-1 row and costs nothing there)
     // On texel column id.x = 0 (lane 0, slot kColSlot; kx = -N/2 dkx is not mirrored there) the
     // reference's layers are not Hermitian-consistent; what they leak is reproduced in closed form:
     //   C1 <- 0,   C2 <- ux (ky - i kx) h,   and pass 2 adds  column_term = (kx + i ux) h  to its derived  i ky C0.
@@ -723,7 +725,7 @@ struct Pass1 {
             const cplx ih = cmuli(h[j]);
             const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
             if (L == 0) d[j] = cscale(ih, 1.0f + ky * ik[j]);
-            if (L == 1) d[j] = cscale(ih, ux);
+            if (L == 1) d[j] = cscale(ih, ux * (1.0f - ky));  // (1 - ky) hz: pass 2's transform of it is hz + i dhz_dx
             if (L == 2) d[j] = cscale(ih, __builtin_fmaf(-kx, ux, kx));
             if (j == kColSlot && L > 0) {
                 const cplx line = (L == 1) ? cplx{0.0f, 0.0f} : cadd(cscale(h[j], ux * ky), cscale(ih, -(ux * kx)));
@@ -905,32 +907,33 @@ struct Pass2 {
     }
     // ---- compact intermediate (see Pass1::layer_input_c): four transforms from three loaded layers ----
     //   F1 = row transform of  i ky C0 + (-1)^x' P   -> (dhx_dx, dhy_dx)       F3 = of C2  -> (dhy_dz, dhz_dz)
-    //   F2 = of (1 - ky) C1  -> (hz, dhz_dx)   [C1 is Hermitian along ky]        F0 = of C0  -> (hx, hy)
+    //   F2 = of C1 = (1 - ky) hz  -> (hz, dhz_dx)                                F0 = of C0  -> (hx, hy)
     // with element ky-index 0 (lane 0, slot kRow0Slot) of F1..F3 replaced by the separately transformed texel row 0.
     static constexpr int kRow0Slot = 8;  // rot(kRow0Slot) == 0
     static OW_DEV float ky_of(int j, int t, float dky) { return (float)(t + T * (rot(j) - 8)) * dky; }
     // P(ky): one complex per map row y, stored in this kernel's lane order (a lane's 16 values = 128 contiguous bytes)
     OW_HD static constexpr uint32_t pcol_index(int y) { return (uint32_t)(y % T) * 16u + (uint32_t)(y / T); }
-    // d[j] = i ky d[j] + sign * P[y_j]
+    // d[j] = i ky d[j] + sign * P[y_j]; slots j < 8 take the natural-order blocks o = 8..15 of P, slots j >= 8 blocks 0..7: two
+    // halves, so that only eight of P's values are in registers at a time
     static OW_DEV void derive_dx(cplx *d, int t, int xp, float dky, GBuf pcol_c) {
         const float s = (xp & 1) ? -1.0f : 1.0f;
-        cplx p[P];  // natural order o = y / T
 #pragma unroll
-        for (int i = 0; i < P / 2; ++i) {
-            const f32x4 v = gload16(pcol_c, (uint32_t)t * 128u, 16u * (uint32_t)i);
-            p[2 * i] = cplx{v.x, v.y};
-            p[2 * i + 1] = cplx{v.z, v.w};
+        for (int half = 0; half < 2; ++half) {
+            cplx p[P / 2];  // p[k] = P block o = 8 * (1 - half) + k
+#pragma unroll
+            for (int i = 0; i < P / 4; ++i) {
+                const f32x4 v = gload16(pcol_c, (uint32_t)t * 128u, 16u * (uint32_t)(i + (P / 4) * (1 - half)));
+                p[2 * i] = cplx{v.x, v.y};
+                p[2 * i + 1] = cplx{v.z, v.w};
+            }
+#pragma unroll
+            for (int k = 0; k < P / 2; ++k) {
+                const int j = 8 * half + k;  // rot(j) = 8 * (1 - half) + k
+                const float ky = ky_of(j, t, dky);
+                d[j] = cplx{__builtin_fmaf(-ky, d[j].y, s * p[k].x), __builtin_fmaf(ky, d[j].x, s * p[k].y)};
+            }
+            OW_SCHED_FENCE();
         }
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const float ky = ky_of(j, t, dky);
-            const cplx pv = p[rot(j)];
-            d[j] = cplx{__builtin_fmaf(-ky, d[j].y, s * pv.x), __builtin_fmaf(ky, d[j].x, s * pv.y)};
-        }
-    }
-    static OW_DEV void scale_hz(cplx *d, int t, float dky) {
-#pragma unroll
-        for (int j = 0; j < P; ++j) d[j] = cscale(d[j], 1.0f - ky_of(j, t, dky));
     }
     static OW_DEV void put_row0(cplx *d, int t, cplx r) {
         d[kRow0Slot] = cplx{t == 0 ? r.x : d[kRow0Slot].x, t == 0 ? r.y : d[kRow0Slot].y};
@@ -943,7 +946,8 @@ struct Pass2 {
             const int sl = OutMap<N>::slot_of(o);
             dhx_dx[o] = f1[sl].x;
             const float gx = f1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o]));
-            gxdx[o] = (uint32_t)f2h(gx) | ((uint32_t)f2h(dhx_dx[o]) << 16);
+            // packed HERE (the or / shift are pure and would otherwise sink to the store two transforms later, leaving both halves live)
+            gxdx[o] = (uint32_t)opaque((int)((uint32_t)f2h(gx) | ((uint32_t)f2h(dhx_dx[o]) << 16)));
             if (F32) {
                 f32_put(f32_c, tex, o, 3, gx);
                 f32_put(f32_c, tex, o, 5, dhx_dx[o]);
@@ -960,7 +964,7 @@ struct Pass2 {
             jpart[o] = (1.0f + jpart[o]) * (1.0f + dhz_dz);
             const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
             const uint32_t gh = f2h(gy);
-            gy_pk[o / 2] = (o & 1) ? (gy_pk[o / 2] | (gh << 16)) : gh;
+            gy_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(gy_pk[o / 2] | (gh << 16))) : gh;
             if (F32) f32_put(f32_c, tex, o, 4, gy);
         }
     }

@@ -413,18 +413,25 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     if (y == 0) {  // wave-uniform, one row per cascade: the three extra transforms of texel row 0, straight to the side buffer
-        auto extra = [&](auto q) {
-            constexpr int Q = decltype(q)::value;
+#pragma unroll
+        for (int Q = 1; Q <= 3; ++Q) {
             cplx d[P];
-            Pass1<N>::template row0_input<Q>(d, h, ik, t, ky, dkx);
+            OW_SCHED_FENCE();
+            {
+                const float kyo = opaque(ky), dkxo = opaque(dkx);
+                const int to = opaque(t);
+#pragma unroll
+                for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
+                if (Q == 1) Pass1<N>::template row0_input<1>(d, h, ik, to, kyo, dkxo);
+                if (Q == 2) Pass1<N>::template row0_input<2>(d, h, ik, to, kyo, dkxo);
+                if (Q == 3) Pass1<N>::template row0_input<3>(d, h, ik, to, kyo, dkxo);
+            }
+            OW_SCHED_FENCE();
             row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
             rs.sync();  // the row region is free again before the next transform writes into it
 #pragma unroll
             for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)Q * 8u, d[OutMap<N>::slot_of(o)]);
-        };
-        extra(std::integral_constant<int, 1>{});
-        extra(std::integral_constant<int, 2>{});
-        extra(std::integral_constant<int, 3>{});
+        }
     }
 
 #pragma unroll
@@ -473,7 +480,6 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     p2_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
     const int xp = row0 + rw;
-    const uint32_t tex = (uint32_t)(xp * N + t);
     const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
     const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
     const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
@@ -482,8 +488,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
     const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
     const float dky = (2.0f * kPi) / cf.tile_y;
-    // texel row 0's three transforms at this x' (ky-index 0 of F1..F3)
-    const cplx r1 = gload8(rrow_c, (uint32_t)xp * 32u, 8u), r2 = gload8(rrow_c, (uint32_t)xp * 32u, 16u), r3 = gload8(rrow_c, (uint32_t)xp * 32u, 24u);
+    // texel row 0's three transforms at this x' (ky-index 0 of F1..F3): entry q of the side buffer
+    auto side_row = [&](int q) { return gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)q * 8u); };
 
     float jpart[P];   // dhx_dx after F1, (1 + dhx_dx)(1 + dhz_dz) after F3
     uint32_t gxdx[P], gy_pk[P / 2];
@@ -491,39 +497,47 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
         cplx f1[P];
         OW_SCHED_FENCE();
         Pass2<N>::template load_layer<AUX_T>(f1, t, xp, 0, T_c);
+        const cplx r1 = side_row(1);
         load_twiddles<N>(tw_lds, buf.tw);
         Pass2<N>::derive_dx(f1, t, xp, dky, pcol_c);
         Pass2<N>::put_row0(f1, t, r1);
-        row_ifft<N>(f1, t, lds_row, tw_lds, rs);
-        Pass2<N>::template after_f1<F32>(f1, jpart, gxdx, tex, f32_c);
+        row_ifft<N>(f1, opaque(t), lds_row, tw_lds, rs);
+        OW_SCHED_FENCE();
+        Pass2<N>::template after_f1<F32>(f1, jpart, gxdx, (uint32_t)(xp * N + opaque(t)), f32_c);
     }
     {
         cplx f3[P];
         OW_SCHED_FENCE();
-        Pass2<N>::template load_layer<AUX_T>(f3, t, xp, 2, T_c);
-        Pass2<N>::put_row0(f3, t, r3);
-        row_ifft<N>(f3, t, lds_row, tw_lds, rs);
-        Pass2<N>::template after_f3<F32>(f3, jpart, gy_pk, tex, f32_c);
+        const int tq = opaque(t);  // per phase: offsets derived from the lane index are recomputed, not carried through the transforms
+        Pass2<N>::template load_layer<AUX_T>(f3, tq, xp, 2, T_c);
+        Pass2<N>::put_row0(f3, tq, side_row(3));
+        row_ifft<N>(f3, opaque(t), lds_row, tw_lds, rs);
+        Pass2<N>::template after_f3<F32>(f3, jpart, gy_pk, (uint32_t)(xp * N + tq), f32_c);
     }
     float hz[P];
     {
         cplx f2[P];
-        uint32_t foam_pk[P / 2];
         OW_SCHED_FENCE();
-        Pass2<N>::template load_layer<AUX_T>(f2, t, xp, 1, T_c);
-        Pass2<N>::load_foam(foam_pk, t, xp, foam_c);
-        Pass2<N>::scale_hz(f2, t, dky);
-        Pass2<N>::put_row0(f2, t, r2);
-        row_ifft<N>(f2, t, lds_row, tw_lds, rs);
-        Pass2<N>::template after_f2<F32, AUX_O>(f2, jpart, gxdx, gy_pk, foam_pk, hz, tex, cf, norm_c, f32_c);
-        Pass2<N>::store_foam(foam_pk, t, xp, foam_c);
+        const int tq = opaque(t);
+        Pass2<N>::template load_layer<AUX_T>(f2, tq, xp, 1, T_c);
+        Pass2<N>::put_row0(f2, tq, side_row(2));
+        uint32_t foam_pk[P / 2];
+        Pass2<N>::load_foam(foam_pk, tq, xp, foam_c);
+        row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
+        OW_SCHED_FENCE();
+        const int tr = opaque(t);
+        Pass2<N>::template after_f2<F32, AUX_O>(f2, jpart, gxdx, gy_pk, foam_pk, hz, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
+        Pass2<N>::store_foam(foam_pk, tr, xp, foam_c);
     }
     {
         cplx f0[P];
         OW_SCHED_FENCE();
-        Pass2<N>::template load_layer<AUX_T>(f0, t, xp, 0, T_c);
-        row_ifft<N>(f0, t, lds_row, tw_lds, rs);
-        Pass2<N>::template after_layer0<F32, AUX_O>(f0, hz, t, xp, tex, disp_c, f32_c);
+        const int tq = opaque(t);
+        Pass2<N>::template load_layer<AUX_T>(f0, tq, xp, 0, T_c);
+        row_ifft<N>(f0, opaque(t), lds_row, tw_lds, rs);
+        OW_SCHED_FENCE();
+        const int tr = opaque(t);
+        Pass2<N>::template after_layer0<F32, AUX_O>(f0, hz, tr, xp, (uint32_t)(xp * N + tr), disp_c, f32_c);
     }
 }
 

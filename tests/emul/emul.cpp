@@ -233,7 +233,6 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
             }
             for (int l = 0; l < NT; ++l) {
                 Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 1, T_c);
-                Pass2<N>::scale_hz(f[l], l % Tn, dky);
                 Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 2));
                 Pass2<N>::load_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
             }
