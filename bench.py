@@ -182,15 +182,17 @@ def main():
     gen.sync()
     p1_ms, p2_ms, launches = gen.timing_read()
     gen.timing(False)
+    family = gen.last_kernel_family()
+    suffix = {"standard": "", "layer_parallel": "_lp", "compact": "c"}[family]
     per_launch = min(C, max(1, (4 << 20) // (n * n)))  # cascades per launch (the runtime batches so that T stays in the Infinity Cache)
     sync_all()
 
     if rank == 0:
         maps = args.steps * C * world
         texels = n * n * per_launch  # per launch (the runtime batches cascades so that T stays in the Infinity Cache)
-        dom = "k_pass1" if p1_ms >= p2_ms else "k_pass2"
+        dom = ("k_pass1" if p1_ms >= p2_ms else "k_pass2") + suffix  # the name rocprofv3 lists the kernel under
         dom_ms = max(p1_ms, p2_ms)
-        dom_bytes = (BYTES_PASS1 if dom == "k_pass1" else BYTES_PASS2) * texels
+        dom_bytes = (BYTES_PASS1 if p1_ms >= p2_ms else BYTES_PASS2) * texels
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_gbps = BYTES_MAP * n * n * maps / elapsed / 1e9 / world  # per-GPU algorithmic GB/s over the whole tick
         traffic = None
@@ -220,7 +222,7 @@ def main():
                                  ("final, untimed" if world > 1 else "none"),
                        **({"rehearsal": f"backend={args.backend}, share_gpu={args.share_gpu}: NOT a measurement"}
                           if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_family": family, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
                          "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5), "launches_timed": launches,

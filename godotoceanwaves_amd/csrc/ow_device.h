@@ -906,8 +906,8 @@ struct Pass2 {
         }
     }
     // ---- compact intermediate (see Pass1::layer_input_c): four transforms from three loaded layers ----
-    //   F1 = row transform of  i ky C0 + (-1)^x' P   -> (dhx_dx, dhy_dx)       F3 = of C2  -> (dhy_dz, dhz_dz)
-    //   F2 = of C1 = (1 - ky) hz  -> (hz, dhz_dx)                                F0 = of C0  -> (hx, hy)
+    //   F2 = row transform of C1 = (1 - ky) hz -> (hz, dhz_dx)        F0 = of C0 -> (hx, hy)
+    //   F1 = of  i ky C0 + (-1)^x' P  -> (dhx_dx, dhy_dx)              F3 = of C2 -> (dhy_dz, dhz_dz)
     // with element ky-index 0 (lane 0, slot kRow0Slot) of F1..F3 replaced by the separately transformed texel row 0.
     static constexpr int kRow0Slot = 8;  // rot(kRow0Slot) == 0
     static OW_DEV float ky_of(int j, int t, float dky) { return (float)(t + T * (rot(j) - 8)) * dky; }
@@ -938,46 +938,63 @@ struct Pass2 {
     static OW_DEV void put_row0(cplx *d, int t, cplx r) {
         d[kRow0Slot] = cplx{t == 0 ? r.x : d[kRow0Slot].x, t == 0 ? r.y : d[kRow0Slot].y};
     }
-    // F1 done: dhx_dx (kept in FP32 for the Jacobian) and gx; gxdx[o] = halves (gx | dhx_dx << 16) for the normal map
+    // Order of the four transforms: F2, F0, F1, F3.  C0 feeds both F0 and F1; it is loaded ONCE and a copy stays in registers
+    // across F0's transform (re-reading it two transforms later would miss the L2 and put the fourth layer's bytes back on
+    // the memory interface).  What waits in registers between the phases:
+    //   after F2: hz as halves, two per word (8) + c2 = dhz_dx^2 (16)         [+ the copy of C0 (32) during F0]
+    //   after F0: displacement stored; c2                                      after F1: c2, dhx_dx (16), gx halves (8)
+    //   after F3: Jacobian = (1 + dhx_dx)(1 + dhz_dz) - c2 -> foam, gy, normal map store
     template <bool F32>
-    static OW_DEV void after_f1(const cplx *f1, float *dhx_dx, uint32_t *gxdx, uint32_t tex, GBuf f32_c) {
+    static OW_DEV void after_f2(const cplx *f2, uint32_t *hz_pk, float *c2, uint32_t tex, GBuf f32_c) {
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            const float hz = f2[sl].x, dhz_dx = f2[sl].y;
+            c2[o] = dhz_dx * dhz_dx;
+            const uint32_t hh = f2h(hz);
+            // packed HERE (pure ops would otherwise sink to the store, leaving both halves live across two transforms)
+            hz_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(hz_pk[o / 2] | (hh << 16))) : hh;
+            if (F32) f32_put(f32_c, tex, o, 2, hz);
+        }
+    }
+    template <bool F32, int AUX>
+    static OW_DEV void after_f0(const cplx *f0, const uint32_t *hz_pk, int t, int xp, uint32_t tex, GBuf disp_c, GBuf f32_c) {
+        const uint16_t w = (uint16_t)(((xp ^ t) & 1) << 15);  // see after_layer0
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const int sl = OutMap<N>::slot_of(o);
+            const uint16_t hz_h = (uint16_t)((hz_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
+            gstore8h<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(f0[sl].x), f2h(f0[sl].y), hz_h, w});
+            if (F32) {
+                f32_put(f32_c, tex, o, 0, f0[sl].x);
+                f32_put(f32_c, tex, o, 1, f0[sl].y);
+            }
+        }
+    }
+    template <bool F32>
+    static OW_DEV void after_f1(const cplx *f1, float *dhx_dx, uint32_t *gx_pk, uint32_t tex, GBuf f32_c) {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
             const int sl = OutMap<N>::slot_of(o);
             dhx_dx[o] = f1[sl].x;
             const float gx = f1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o]));
-            // packed HERE (the or / shift are pure and would otherwise sink to the store two transforms later, leaving both halves live)
-            gxdx[o] = (uint32_t)opaque((int)((uint32_t)f2h(gx) | ((uint32_t)f2h(dhx_dx[o]) << 16)));
+            const uint32_t gh = f2h(gx);
+            gx_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(gx_pk[o / 2] | (gh << 16))) : gh;
             if (F32) {
                 f32_put(f32_c, tex, o, 3, gx);
                 f32_put(f32_c, tex, o, 5, dhx_dx[o]);
             }
         }
     }
-    // F3 done: jpart = (1 + dhx_dx)(1 + dhz_dz) replaces dhx_dx; gy halves, two per word
-    template <bool F32>
-    static OW_DEV void after_f3(const cplx *f3, float *jpart, uint32_t *gy_pk, uint32_t tex, GBuf f32_c) {
+    // fft_unpack.glsl:55-67 with everything at hand
+    template <bool F32, int AUX>
+    static OW_DEV void after_f3(const cplx *f3, const float *dhx_dx, const float *c2, const uint32_t *gx_pk, uint32_t *foam_pk,
+                                uint32_t tex, const CascadeFrame &cf, GBuf norm_c, GBuf f32_c) {
 #pragma unroll
         for (int o = 0; o < P; ++o) {
             const int sl = OutMap<N>::slot_of(o);
             const float dhy_dz = f3[sl].x, dhz_dz = f3[sl].y;
-            jpart[o] = (1.0f + jpart[o]) * (1.0f + dhz_dz);
-            const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
-            const uint32_t gh = f2h(gy);
-            gy_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(gy_pk[o / 2] | (gh << 16))) : gh;
-            if (F32) f32_put(f32_c, tex, o, 4, gy);
-        }
-    }
-    // F2 done: Jacobian -> foam recurrence (fft_unpack.glsl:55-64), normal map store; hz stays for the displacement store
-    template <bool F32, int AUX>
-    static OW_DEV void after_f2(const cplx *f2, const float *jpart, const uint32_t *gxdx, const uint32_t *gy_pk, uint32_t *foam_pk,
-                                float *hz, uint32_t tex, const CascadeFrame &cf, GBuf norm_c, GBuf f32_c) {
-#pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int sl = OutMap<N>::slot_of(o);
-            hz[o] = f2[sl].x;
-            const float dhz_dx = f2[sl].y;
-            const float jac = jpart[o] - dhz_dx * dhz_dx;
+            const float jac = (1.0f + dhx_dx[o]) * (1.0f + dhz_dz) - c2[o];
             const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
             float foam = h2f((uint16_t)((foam_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu));
             foam = mul_rn(foam, cf.foam_decay);
@@ -985,10 +1002,11 @@ struct Pass2 {
             foam = fminf(fmaxf(foam, 0.0f), 1.0f);
             const uint32_t foam_h = f2h(foam);
             foam_pk[o / 2] = (o & 1) ? ((foam_pk[o / 2] & 0xFFFFu) | (foam_h << 16)) : ((foam_pk[o / 2] & 0xFFFF0000u) | foam_h);
-            const uint16_t gy_h = (uint16_t)((gy_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
-            gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u,
-                          u16x4{(uint16_t)(gxdx[o] & 0xFFFFu), gy_h, (uint16_t)(gxdx[o] >> 16), (uint16_t)foam_h});
+            const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
+            const uint16_t gx_h = (uint16_t)((gx_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
+            gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{gx_h, f2h(gy), f2h(dhx_dx[o]), (uint16_t)foam_h});
             if (F32) {
+                f32_put(f32_c, tex, o, 4, gy);
                 f32_put(f32_c, tex, o, 6, foam);
                 f32_put(f32_c, tex, o, 7, jac);
             }

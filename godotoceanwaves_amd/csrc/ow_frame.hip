@@ -14,7 +14,7 @@ static void launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const LaunchT
 }
 
 // family the runtime picks for batches too large for the layer-parallel kernels, where the compact kernels exist
-constexpr int kAutoLargeFamily = 1;
+constexpr int kAutoLargeFamily = 3;  // measured (scripts/mode_bench.py): 1024^2 x 4 65.1 vs 71.2 us, 1024^2 x 2 42.0 vs 44.5, 2048^2 x 1 71.7 vs 81.5
 
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 

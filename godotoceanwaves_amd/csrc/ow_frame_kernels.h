@@ -491,53 +491,56 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     // texel row 0's three transforms at this x' (ky-index 0 of F1..F3): entry q of the side buffer
     auto side_row = [&](int q) { return gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)q * 8u); };
 
-    float jpart[P];   // dhx_dx after F1, (1 + dhx_dx)(1 + dhz_dz) after F3
-    uint32_t gxdx[P], gy_pk[P / 2];
+    uint32_t hz_pk[P / 2];
+    float c2[P];
     {
-        cplx f1[P];
+        cplx f2[P];
         OW_SCHED_FENCE();
-        Pass2<N>::template load_layer<AUX_T>(f1, t, xp, 0, T_c);
-        const cplx r1 = side_row(1);
+        Pass2<N>::template load_layer<AUX_T>(f2, t, xp, 1, T_c);
+        const cplx r2 = side_row(2);
         load_twiddles<N>(tw_lds, buf.tw);
-        Pass2<N>::derive_dx(f1, t, xp, dky, pcol_c);
-        Pass2<N>::put_row0(f1, t, r1);
-        row_ifft<N>(f1, opaque(t), lds_row, tw_lds, rs);
+        Pass2<N>::put_row0(f2, t, r2);
+        row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
-        Pass2<N>::template after_f1<F32>(f1, jpart, gxdx, (uint32_t)(xp * N + opaque(t)), f32_c);
+        Pass2<N>::template after_f2<F32>(f2, hz_pk, c2, (uint32_t)(xp * N + opaque(t)), f32_c);
+    }
+    cplx c0[P];  // C0, loaded once: transformed as it is (F0) and, from this copy, as i ky C0 + P (F1)
+    {
+        cplx f0[P];
+        OW_SCHED_FENCE();
+        const int tq = opaque(t);  // per phase: offsets derived from the lane index are recomputed, not carried through the transforms
+        Pass2<N>::template load_layer<AUX_T>(c0, tq, xp, 0, T_c);
+#pragma unroll
+        for (int j = 0; j < P; ++j) f0[j] = c0[j];
+        row_ifft<N>(f0, opaque(t), lds_row, tw_lds, rs);
+        OW_SCHED_FENCE();
+        const int tr = opaque(t);
+        Pass2<N>::template after_f0<F32, AUX_O>(f0, hz_pk, tr, xp, (uint32_t)(xp * N + tr), disp_c, f32_c);
+    }
+    float dhx_dx[P];
+    uint32_t gx_pk[P / 2];
+    {
+        OW_SCHED_FENCE();
+        const int tq = opaque(t);
+        Pass2<N>::derive_dx(c0, tq, xp, dky, pcol_c);
+        Pass2<N>::put_row0(c0, tq, side_row(1));
+        row_ifft<N>(c0, opaque(t), lds_row, tw_lds, rs);
+        OW_SCHED_FENCE();
+        Pass2<N>::template after_f1<F32>(c0, dhx_dx, gx_pk, (uint32_t)(xp * N + opaque(t)), f32_c);
     }
     {
         cplx f3[P];
         OW_SCHED_FENCE();
-        const int tq = opaque(t);  // per phase: offsets derived from the lane index are recomputed, not carried through the transforms
+        const int tq = opaque(t);
         Pass2<N>::template load_layer<AUX_T>(f3, tq, xp, 2, T_c);
         Pass2<N>::put_row0(f3, tq, side_row(3));
-        row_ifft<N>(f3, opaque(t), lds_row, tw_lds, rs);
-        Pass2<N>::template after_f3<F32>(f3, jpart, gy_pk, (uint32_t)(xp * N + tq), f32_c);
-    }
-    float hz[P];
-    {
-        cplx f2[P];
-        OW_SCHED_FENCE();
-        const int tq = opaque(t);
-        Pass2<N>::template load_layer<AUX_T>(f2, tq, xp, 1, T_c);
-        Pass2<N>::put_row0(f2, tq, side_row(2));
         uint32_t foam_pk[P / 2];
         Pass2<N>::load_foam(foam_pk, tq, xp, foam_c);
-        row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
+        row_ifft<N>(f3, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         const int tr = opaque(t);
-        Pass2<N>::template after_f2<F32, AUX_O>(f2, jpart, gxdx, gy_pk, foam_pk, hz, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
+        Pass2<N>::template after_f3<F32, AUX_O>(f3, dhx_dx, c2, gx_pk, foam_pk, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
         Pass2<N>::store_foam(foam_pk, tr, xp, foam_c);
-    }
-    {
-        cplx f0[P];
-        OW_SCHED_FENCE();
-        const int tq = opaque(t);
-        Pass2<N>::template load_layer<AUX_T>(f0, tq, xp, 0, T_c);
-        row_ifft<N>(f0, opaque(t), lds_row, tw_lds, rs);
-        OW_SCHED_FENCE();
-        const int tr = opaque(t);
-        Pass2<N>::template after_layer0<F32, AUX_O>(f0, hz, tr, xp, (uint32_t)(xp * N + tr), disp_c, f32_c);
     }
 }
 

@@ -389,6 +389,8 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     return OW_OK;
 }
 
+int32_t ow_last_kernel_family(const ow_context *c) { return c ? c->last_family : 0; }
+
 int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_cascades_remaining : 0; }
 
 ow_status ow_sync(ow_context *c) {

@@ -261,6 +261,12 @@ class WaveGenerator:
         _lib.check(self._lib.ow_get_intermediate(self.context, cascade, out.ctypes.data))
         return out
 
+    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact"}
+
+    def last_kernel_family(self):
+        """which kernels the most recent batch ran with: "standard", "layer_parallel", "compact" (None before the first launch)"""
+        return self.KERNEL_FAMILIES[int(self._lib.ow_last_kernel_family(self.context))]
+
     def timing(self, enable):
         _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
 

@@ -75,12 +75,13 @@ typedef struct ow_config {
 
 #define OW_FLAG_DEBUG_F32 1u /* also keep 8 pre-quantisation FP32 channels per texel (parity tests) */
 /* Kernel family.  By default the runtime picks per batch: the layer-parallel kernels (one lane group per row AND
- * packed layer) when a batch is too small to fill the chip, the standard ones (one lane group per row, layers in
- * sequence) otherwise.  These two flags pin the choice (tests, measurements). */
+ * packed layer) when a batch is too small to fill the chip; otherwise the compact-intermediate kernels where they
+ * exist (map_size >= 1024) and the standard ones (one lane group per row, four layers in sequence, the reference's
+ * packing) elsewhere.  These flags pin the choice (tests, measurements). */
 #define OW_FLAG_KERNELS_STANDARD 2u
 #define OW_FLAG_KERNELS_LAYER_PARALLEL 4u
-/* Compact-intermediate kernels (map_size >= 1024): three packed layers cross the intermediate instead of the
- * reference's four; ow_get_intermediate is not available for batches that used them. */
+/* Compact-intermediate kernels (map_size >= 1024; standard ones below that): three packed layers cross the
+ * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them. */
 #define OW_FLAG_KERNELS_COMPACT 8u
 
 typedef struct ow_context ow_context;
@@ -206,6 +207,10 @@ double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_
  * figure is the kernel's begin -> end exactly as a rocprofv3 kernel trace reports it.  Throughput runs keep it off. */
 ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
+
+/* Kernel family the most recent batch was launched with: 1 = standard (k_pass1 / k_pass2), 2 = layer-parallel
+ * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c); 0 before the first launch. */
+int32_t ow_last_kernel_family(const ow_context *ctx);
 
 /* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
  * and then `reps` of pass 2 with the arguments of the most recent batch, bracketed by hipEvents on the context's

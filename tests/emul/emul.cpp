@@ -204,49 +204,51 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
             }
         }
     }
-    {   // ---- pass 2: F1, F3, F2, F0 ----
-        static cplx f[NT][P];
-        static float jpart[NT][P], hz[NT][P];
-        static uint32_t gxdx[NT][P], gy_pk[NT][P / 2], foam_pk[NT][P / 2];
+    {   // ---- pass 2: F2, F0, F1, F3 ----
+        static cplx f[NT][P], c0[NT][P];
+        static float c2[NT][P], dxx[NT][P];
+        static uint32_t hz_pk[NT][P / 2], gx_pk[NT][P / 2], foam_pk[NT][P / 2];
         for (int row0 = 0; row0 < N; row0 += kWgRows) {
             auto xp_of = [&](int l) { return row0 + l / Tn; };
             auto tex_of = [&](int l) { return (uint32_t)(xp_of(l) * N + l % Tn); };
             auto r_of = [&](int l, int q) { return gload8(rrow_c, (uint32_t)xp_of(l) * 32u, (uint32_t)q * 8u); };
             for (int l = 0; l < NT; ++l) {
-                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 0, T_c);
-                Pass2<N>::derive_dx(f[l], l % Tn, xp_of(l), dky, pcol_c);
-                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 1));
+                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 1, T_c);
+                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 2));
             }
             w.row_ifft(f);
             for (int l = 0; l < NT; ++l) {
-                if (f32) Pass2<N>::template after_f1<true>(f[l], jpart[l], gxdx[l], tex_of(l), f32_c);
-                else Pass2<N>::template after_f1<false>(f[l], jpart[l], gxdx[l], tex_of(l), f32_c);
+                if (f32) Pass2<N>::template after_f2<true>(f[l], hz_pk[l], c2[l], tex_of(l), f32_c);
+                else Pass2<N>::template after_f2<false>(f[l], hz_pk[l], c2[l], tex_of(l), f32_c);
+            }
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::template load_layer<0>(c0[l], l % Tn, xp_of(l), 0, T_c);
+                for (int j = 0; j < P; ++j) f[l][j] = c0[l][j];
+            }
+            w.row_ifft(f);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_f0<true, 0>(f[l], hz_pk[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
+                else Pass2<N>::template after_f0<false, 0>(f[l], hz_pk[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
+            }
+            for (int l = 0; l < NT; ++l) {
+                Pass2<N>::derive_dx(c0[l], l % Tn, xp_of(l), dky, pcol_c);
+                Pass2<N>::put_row0(c0[l], l % Tn, r_of(l, 1));
+            }
+            w.row_ifft(c0);
+            for (int l = 0; l < NT; ++l) {
+                if (f32) Pass2<N>::template after_f1<true>(c0[l], dxx[l], gx_pk[l], tex_of(l), f32_c);
+                else Pass2<N>::template after_f1<false>(c0[l], dxx[l], gx_pk[l], tex_of(l), f32_c);
             }
             for (int l = 0; l < NT; ++l) {
                 Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 2, T_c);
                 Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 3));
-            }
-            w.row_ifft(f);
-            for (int l = 0; l < NT; ++l) {
-                if (f32) Pass2<N>::template after_f3<true>(f[l], jpart[l], gy_pk[l], tex_of(l), f32_c);
-                else Pass2<N>::template after_f3<false>(f[l], jpart[l], gy_pk[l], tex_of(l), f32_c);
-            }
-            for (int l = 0; l < NT; ++l) {
-                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 1, T_c);
-                Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 2));
                 Pass2<N>::load_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
             }
             w.row_ifft(f);
             for (int l = 0; l < NT; ++l) {
-                if (f32) Pass2<N>::template after_f2<true, 0>(f[l], jpart[l], gxdx[l], gy_pk[l], foam_pk[l], hz[l], tex_of(l), cf, norm_c, f32_c);
-                else Pass2<N>::template after_f2<false, 0>(f[l], jpart[l], gxdx[l], gy_pk[l], foam_pk[l], hz[l], tex_of(l), cf, norm_c, f32_c);
+                if (f32) Pass2<N>::template after_f3<true, 0>(f[l], dxx[l], c2[l], gx_pk[l], foam_pk[l], tex_of(l), cf, norm_c, f32_c);
+                else Pass2<N>::template after_f3<false, 0>(f[l], dxx[l], c2[l], gx_pk[l], foam_pk[l], tex_of(l), cf, norm_c, f32_c);
                 Pass2<N>::store_foam(foam_pk[l], l % Tn, xp_of(l), foam_c);
-            }
-            for (int l = 0; l < NT; ++l) Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 0, T_c);
-            w.row_ifft(f);
-            for (int l = 0; l < NT; ++l) {
-                if (f32) Pass2<N>::template after_layer0<true, 0>(f[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
-                else Pass2<N>::template after_layer0<false, 0>(f[l], hz[l], l % Tn, xp_of(l), tex_of(l), disp_c, f32_c);
             }
         }
     }

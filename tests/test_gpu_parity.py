@@ -168,11 +168,13 @@ def test_full_size_properties(n):
             assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, name
 
 
+@pytest.mark.parametrize("kernels", [None, "standard"])
 @pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (2048, [0, 2])])
-def test_batched_launches_match_oracle(n, ids):
+def test_batched_launches_match_oracle(n, ids, kernels):
     """More cascades than one pair of launches takes (the runtime batches at 4 Mi texels and reuses the scratch
-    intermediate between batches): every cascade still matches the oracle, two frames."""
-    gen, params = make_gen(n, ids)
+    intermediate between batches): every cascade still matches the oracle, two frames.  kernels=None is the runtime's own
+    choice (the compact-intermediate kernels at these sizes)."""
+    gen, params = make_gen(n, ids, kernels=kernels)
     og = H.oracle_generator(n, ids)
     for frame in range(2):
         gen.update_all(UPDATE_DELTA, params)
@@ -185,9 +187,15 @@ def test_batched_launches_match_oracle(n, ids):
                 assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
             else:
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+    family = gen.last_kernel_family()        # of the LAST batch (1024^2: cascade 0 alone -> layer-parallel; 2048^2: one cascade -> compact)
+    assert family == "standard" if kernels == "standard" else family in ("compact", "layer_parallel")
     with pytest.raises(_lib.OceanWavesError):
         gen.get_intermediate(len(ids) - 1)   # first batch's scratch has been overwritten by the last batch (update_all drains highest index first)
-    assert gen.get_intermediate(0).shape == (4, n, n, 2)
+    if family == "compact":
+        with pytest.raises(_lib.OceanWavesError):
+            gen.get_intermediate(0)          # the compact intermediate has no counterpart in the reference's fft_buffer
+    else:
+        assert gen.get_intermediate(0).shape == (4, n, n, 2)
 
 
 def _edge_cases():
