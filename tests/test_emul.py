@@ -67,12 +67,16 @@ def test_row_ifft_is_unnormalised_inverse_dft(emul, n):
 
 
 @pytest.mark.parametrize("intermediate", ["reference_layout", "compact"])
-@pytest.mark.parametrize("n,ci", [(128, 0), (256, 2), (512, 1)])
+@pytest.mark.parametrize("n,ci", [(128, 0), (256, 2), (512, 1), (128, "non_square_tile"), (128, "late_time")])
 def test_emulated_kernels_match_oracle(emul, n, ci, intermediate):
     """both kernel families: the four-layer intermediate of the reference and the compact three-layer one
     (Pass1::layer_input_c, tests/test_compact_math.py)"""
     frame_fn = emul.emul_frame if intermediate == "reference_layout" else emul.emul_frame_compact
-    p = cascade_preset(ci)
+    if isinstance(ci, str):
+        from edge_presets import edge_presets
+        p = edge_presets()[ci]
+    else:
+        p = cascade_preset(ci)
     pc = H.spectrum_pc(p)
     epc = PC(p["spectrum_seed"][0], p["spectrum_seed"][1], p["tile_length"][0], p["tile_length"][1], pc.alpha, pc.peak_frequency,
              pc.wind_speed, pc.angle, DEPTH, p["swell"], p["detail"], p["spread"])
@@ -82,7 +86,8 @@ def test_emulated_kernels_match_oracle(emul, n, ci, intermediate):
     assert np.array_equal(h0, O.spectrum_compute(n, pc))
     assert np.array_equal(om, O.omega(n, p["tile_length"], DEPTH))
 
-    g = H.oracle_generator(n, [ci])
+    g = O.Generator(n, 1, DEPTH)
+    H.set_params(g.params[0], p)
     norm = np.zeros((n, n, 4), np.uint16)
     foam = np.zeros((n * n,), np.uint16)  # the context's private FP16 foam plane (device order)
     for frame in range(3):

@@ -266,3 +266,32 @@ def test_compact_intermediate_kernels_match_oracle(n, ids):
     with pytest.raises(_lib.OceanWavesError) as e:
         gen.get_intermediate(0)
     assert e.value.status == _lib.OW_ERR_STATE
+
+
+@pytest.mark.parametrize("names", [("non_square_tile", "late_time"), ("gale_long_fetch", "whitecap_foam_extremes"),
+                                   ("wrapping_seed", "swell_spread_detail_extremes")])
+def test_compact_kernels_on_parameter_range_edges(names):
+    """the closed-form Nyquist-line handling of the compact intermediate on non-square tiles, t = 0, the largest phases,
+    the smallest and largest tiles (1024^2, two cascades per launch so that the runtime picks the compact kernels)"""
+    from edge_presets import edge_presets
+    n, presets = 1024, [edge_presets()[k] for k in names]
+    gen = WaveGenerator()
+    gen.map_size, gen.debug_f32 = n, True
+    gen.init_gpu(2)
+    params = [WaveCascadeParameters(**p) for p in presets]
+    og = O.Generator(n, 2, DEPTH)
+    for i, p in enumerate(presets):
+        H.set_params(og.params[i], p)
+    for _ in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == "compact"
+    for i in range(2):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        assert np.isfinite(f32).all()
+        for c, cname in enumerate(H.CHANNELS):
+            if cname == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (names[i], cname)
+            elif np.abs(ref[..., c]).max() > 0:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (names[i], cname, H.relmax(f32[..., c], ref[..., c]))
