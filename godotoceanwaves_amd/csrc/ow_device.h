@@ -709,9 +709,10 @@ struct Pass1 {
     // Off the two Nyquist lines all eight fields of spectrum_modulate.glsl:72-82 are real and three of them are
     // i*ky times three others (dhx_dx = i ky hx, dhy_dx = i ky hy, dhz_dx = i ky hz), ky being the axis PASS 2
     // transforms: pass 2 can form them itself from what it loads.  Only five real fields cross the intermediate:
-    //   C0 = hx + i hy = i (1 + uy) h      C1 = (1 - ky) hz = (1 - ky) i ux h      C2 = dhy_dz + i dhz_dz = i kx (1 - ux) h
-    // (hz travels alone: its spectrum is Hermitian along ky, so the transform of (1 - ky) hz = hz + i (i ky hz) is
-    // hz + i dhz_dx, two real fields again; the factor is uniform over a pass-1 row and costs nothing there)
+    //   C0 = hx + i hy = i (1 + uy) h      C1 = hz = i ux h  (alone)      C2 = dhy_dz + i dhz_dz = i kx (1 - ux) h
+    // hz travels alone because its spectrum is Hermitian along ky: pass 2's transform of (1 - ky) hz = hz + i (i ky hz) is
+    // hz + i dhz_dx, two real fields again -- and only the rows with ky >= 0 (y >= N/2) have to be transformed and stored
+    // at all: row N - y is the conjugate (Pass2::load_c1).  Blocks of the lower half skip layer 1.
     // On texel column id.x = 0 (lane 0, slot kColSlot; kx = -N/2 dkx is not mirrored there) the
     // reference's layers are not Hermitian-consistent; what they leak is reproduced in closed form:
     //   C1 <- 0,   C2 <- ux (ky - i kx) h,   and pass 2 adds  column_term = (kx + i ux) h  to its derived  i ky C0.
@@ -725,7 +726,7 @@ struct Pass1 {
             const cplx ih = cmuli(h[j]);
             const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
             if (L == 0) d[j] = cscale(ih, 1.0f + ky * ik[j]);
-            if (L == 1) d[j] = cscale(ih, ux * (1.0f - ky));  // (1 - ky) hz: pass 2's transform of it is hz + i dhz_dx
+            if (L == 1) d[j] = cscale(ih, ux);
             if (L == 2) d[j] = cscale(ih, __builtin_fmaf(-kx, ux, kx));
             if (j == kColSlot && L > 0) {
                 const cplx line = (L == 1) ? cplx{0.0f, 0.0f} : cadd(cscale(h[j], ux * ky), cscale(ih, -(ux * kx)));
@@ -906,7 +907,7 @@ struct Pass2 {
         }
     }
     // ---- compact intermediate (see Pass1::layer_input_c): four transforms from three loaded layers ----
-    //   F2 = row transform of C1 = (1 - ky) hz -> (hz, dhz_dx)        F0 = of C0 -> (hx, hy)
+    //   F2 = row transform of (1 - ky) C1 -> (hz, dhz_dx)             F0 = of C0 -> (hx, hy)
     //   F1 = of  i ky C0 + (-1)^x' P  -> (dhx_dx, dhy_dx)              F3 = of C2 -> (dhy_dz, dhz_dz)
     // with element ky-index 0 (lane 0, slot kRow0Slot) of F1..F3 replaced by the separately transformed texel row 0.
     static constexpr int kRow0Slot = 8;  // rot(kRow0Slot) == 0
@@ -933,6 +934,29 @@ struct Pass2 {
                 d[j] = cplx{__builtin_fmaf(-ky, d[j].y, s * p[k].x), __builtin_fmaf(ky, d[j].x, s * p[k].y)};
             }
             OW_SCHED_FENCE();
+        }
+    }
+    // C1 = (1 - ky) hz for all y of row x' from the stored half S(x', y >= N/2) = row transform of hz:
+    //   slots j < 8  (y = t + T (8 + j) >= N/2):  (1 - ky) S(y)
+    //   slots j >= 8 (y = t + T (j - 8) <  N/2):  (1 - ky) conj(S(N - y)),  N - y = (N - t) - T (j - 8): the lanes of the wave read
+    //   the same lines in reverse order (L1 hits); slot 8 of lane 0 (y = 0) reads nonsense and is replaced by the row-0 entry.
+    template <int AUX>
+    static OW_DEV void load_c1(cplx *d, int t, int xp, float dky, GBuf T_c) {
+        static_assert(T >= 16, "the mirrored offsets below assume that T is a multiple of the 16-row line");
+        const uint32_t voff = t_voff(t, xp);
+        // lane part of the mirrored address for the smallest mirrored y the lane needs (j = 15): (N - t) - 7 T
+        const uint32_t voff_m = t_unit(N, 0, xp, N - t - 7 * T) * 8u;
+        const float kyb = (float)t * dky;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const float sc = 1.0f - __builtin_fmaf((float)(T * (rot(j) - 8)), dky, kyb);  // 1 - ky(y_j)
+            if (j < P / 2) {
+                const cplx v = gload8<AUX>(T_c, voff, t_soff(1, rot(j)));
+                d[j] = cscale(v, sc);
+            } else {
+                const cplx v = gload8<AUX>(T_c, voff_m, (t_unit(N, 1, 0, 0) + t_unit(N, 0, 0, T * (15 - j))) * 8u);
+                d[j] = cplx{v.x * sc, v.y * -sc};
+            }
         }
     }
     static OW_DEV void put_row0(cplx *d, int t, cplx r) {

@@ -434,8 +434,11 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
         }
     }
 
+    // rows below N/2 skip layer 1: hz of row N - y is the conjugate of row y's (block-uniform: a block's 8 rows lie in one half)
+    const bool lower = row0 < N / 2;
 #pragma unroll
     for (int L = 0; L < LC; ++L) {
+        if (L == 1 && lower) continue;
         cplx d[P];
         OW_SCHED_FENCE();
         {
@@ -443,8 +446,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
             const int to = opaque(t);
 #pragma unroll
             for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
-            auto drain = [&](int g) {
-                if (L > 0) Pass1<N>::template stage_store_chunk<AUX_T>(tau, L - 1, row0, rows_lds, T_c, g);
+            auto drain = [&](int g) {  // the previous layer that was staged: L - 1, or 0 when layer 1 was skipped
+                if (L > 0) Pass1<N>::template stage_store_chunk<AUX_T>(tau, (L == 2 && lower) ? 0 : L - 1, row0, rows_lds, T_c, g);
             };
             if (L == 0) Pass1<N>::template layer_input_c<0>(d, h, ik, to, kyo, dkxo, drain);
             if (L == 1) Pass1<N>::template layer_input_c<1>(d, h, ik, to, kyo, dkxo, drain);
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     {
         cplx f2[P];
         OW_SCHED_FENCE();
-        Pass2<N>::template load_layer<AUX_T>(f2, t, xp, 1, T_c);
+        Pass2<N>::template load_c1<AUX_T>(f2, t, xp, dky, T_c);
         const cplx r2 = side_row(2);
         load_twiddles<N>(tw_lds, buf.tw);
         Pass2<N>::put_row0(f2, t, r2);

@@ -191,6 +191,7 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
                 }
             }
             for (int L = 0; L < Pass1<N>::kCompactLayers; ++L) {
+                if (L == 1 && row0 < N / 2) continue;  // hz of the lower rows is the conjugate of the mirrored rows': not transformed
                 for (int l = 0; l < NT; ++l) {
                     const int y = row0 + l / Tn, t = l % Tn;
                     const float ky = (float)(y - N / 2) * dky;
@@ -213,7 +214,7 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
             auto tex_of = [&](int l) { return (uint32_t)(xp_of(l) * N + l % Tn); };
             auto r_of = [&](int l, int q) { return gload8(rrow_c, (uint32_t)xp_of(l) * 32u, (uint32_t)q * 8u); };
             for (int l = 0; l < NT; ++l) {
-                Pass2<N>::template load_layer<0>(f[l], l % Tn, xp_of(l), 1, T_c);
+                Pass2<N>::template load_c1<0>(f[l], l % Tn, xp_of(l), dky, T_c);
                 Pass2<N>::put_row0(f[l], l % Tn, r_of(l, 2));
             }
             w.row_ifft(f);
@@ -300,7 +301,6 @@ int emul_frame(int n, const float *h0a, const float *omega, const CascadeFrame *
 int emul_frame_compact(int n, const float *h0a, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
                        uint16_t *norm, uint16_t *foam, float *f32) {
     switch (n) {
-        case 128: frame_compact<128>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 256: frame_compact<256>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 512: frame_compact<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 1024: frame_compact<1024>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;

@@ -5,9 +5,9 @@ The reference transforms four packed complex layers (spectrum_modulate.glsl:72-8
 (texel column id.x = 0 and texel row id.y = 0) all eight fields are real, and three of them are derivatives, along the
 axis the SECOND row pass transforms, of three others:
     dhx_dx = i ky hx,   dhy_dx = i ky hy,   dhz_dx = i ky hz        (spectrum_modulate.glsl:72-82)
-so only five real fields have to cross the intermediate: T0 = hx + i hy, T1 = (1 - ky) hz (hz alone is Hermitian along
-ky, which is what lets (1 - ky) hz carry hz + i dhz_dx through ONE transform; the factor is uniform over a pass-1 row),
-T2 = dhy_dz + i dhz_dz -- three layers instead of four.
+so only five real fields have to cross the intermediate: T0 = hx + i hy, T1 = hz (alone: Hermitian along ky, which is
+what lets (1 - ky) T1 carry hz + i dhz_dx through ONE transform, and why only the rows ky >= 0 of T1 are kept),
+T2 = dhy_dz + i dhz_dz -- two and a half layers instead of four.
 On the Nyquist lines the reference's packed layers are not Hermitian-consistent (odd multipliers meet an un-mirrored
 wave number) and leak a few % into the other component; those lines are handled in closed form:
     column id.x = 0:  T1 gets 0, T2 gets ux (ky - i kx) h, and pass 2 adds P(ky) = (kx + i ux) h to the derived i ky T0
@@ -28,7 +28,7 @@ def compact_pipeline(n, tile, t, h0, h0m):
     m = np.exp(1j * np.sqrt(T.G * k * np.tanh(k * 20.0)) * t)
     h = h0 * m + h0m * np.conj(m)
     # ---- pass 1: three layers, column id.x = 0 in closed form ----
-    Z0, Z1, Z2 = 1j * (1 + uy) * h, (1 - ky) * 1j * ux * h, 1j * kx * (1 - ux) * h
+    Z0, Z1, Z2 = 1j * (1 + uy) * h, 1j * ux * h, 1j * kx * (1 - ux) * h
     col = idx == 0
     Z1 = np.where(col, 0, Z1)
     Z2 = np.where(col, ux * (ky - 1j * kx) * h, Z2)
@@ -42,9 +42,14 @@ def compact_pipeline(n, tile, t, h0, h0m):
     R = [None] + [np.fft.ifft(q) * n for q in (Q1, Q2, Q3)]
     # ---- pass 2: four transforms per row x' ----
     kyv = ky[:, 0]
+    # only the rows y >= N/2 of T1 are kept; row N - y is the conjugate (T1 = hz alone is Hermitian along the second axis)
+    S = Tm[1].copy()
+    S[1:n // 2] = np.nan
+    c1 = S.copy()
+    c1[1:n // 2] = np.conj(S[n - np.arange(1, n // 2)])
     out = np.zeros((4, n, n), complex)
     for xp in range(n):
-        G = [Tm[0][:, xp].copy(), 1j * kyv * Tm[0][:, xp] + P, Tm[1][:, xp].copy(), Tm[2][:, xp].copy()]
+        G = [Tm[0][:, xp].copy(), 1j * kyv * Tm[0][:, xp] + P, (1 - kyv) * c1[:, xp], Tm[2][:, xp].copy()]
         for j in (1, 2, 3):
             G[j][0] = R[j][xp]
         F = [np.fft.ifft(g) * n for g in G]
@@ -63,9 +68,8 @@ def test_three_layer_intermediate_reproduces_the_four_layer_reference(n, tile):
     ref = T.ifft2_ref(T.modulate(n, tile, 20.0, 123.4, h0, h0m))
     out, Tm = compact_pipeline(n, tile, 123.4, h0, h0m)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-12
-    # T1 / (1 - ky) is Hermitian along the second axis (only half of it would have to be stored)
-    hz_t = Tm[1][1:] / (1 - (np.arange(1, n) - n * 0.5) * 2 * np.pi / tile[1])[:, None]
-    assert np.abs(hz_t - np.conj(hz_t[::-1])).max() < 1e-10 * np.abs(hz_t).max()
+    # T1 is Hermitian along the second axis (which is why only half of it is stored)
+    assert np.abs(Tm[1][1:] - np.conj(Tm[1][1:][::-1])).max() < 1e-12 * np.abs(Tm[1]).max()
 
 
 def test_the_nyquist_lines_matter():
