@@ -224,6 +224,9 @@ def main():
                           if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_family": family, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         # what really crossed the memory interface per second (PMC bytes / this run's launch time): the compact
+                         # kernels move fewer bytes than SURVEY 8d's algorithmic 104 B/texel, so `achieved` can exceed it
+                         "traffic_gbps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if (traffic and dom_ms > 0) else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
                          "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5), "launches_timed": launches,
                          "cascades_per_launch": per_launch,

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocean_waves.so")
+# OCEAN_WAVES_LIB: developer override to A/B a differently built library (scripts/build_variant.sh); same loud failure if missing
+LIB_PATH = os.environ.get("OCEAN_WAVES_LIB") or os.path.join(_HERE, "libocean_waves.so")
 
 OW_MAX_CASCADES = 8
 OW_FLAG_DEBUG_F32 = 1
