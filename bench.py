@@ -183,7 +183,7 @@ def main():
     p1_ms, p2_ms, launches = gen.timing_read()
     gen.timing(False)
     family = gen.last_kernel_family()
-    suffix = {"standard": "", "layer_parallel": "_lp", "compact": "c"}[family]
+    suffix = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}[family]
     per_launch = min(C, max(1, (4 << 20) // (n * n)))  # cascades per launch (the runtime batches so that T stays in the Infinity Cache)
     sync_all()
 

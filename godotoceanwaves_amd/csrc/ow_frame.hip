@@ -19,14 +19,19 @@ constexpr int kAutoLargeFamily = 3;  // measured (scripts/mode_bench.py): 1024^2
 bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
 // Kernel family of a batch.  mode: 0 = choose by size, 1 = standard (four-layer intermediate in the reference's packing),
-// 2 = layer-parallel, 3 = compact (three-layer intermediate).  Small batches take the layer-parallel kernels: up to
-// ~1024 waves of row work the standard kernels cannot fill the chip and run at one wave's serial latency.
+// 2 = layer-parallel, 3 = compact (two-and-a-half-layer intermediate), 4 = layer-parallel on the compact intermediate.
+// Small batches take the layer-parallel kernels: up to ~1024 waves of row work the standard kernels cannot fill the chip
+// and run at one wave's serial latency.
 template <int N>
 static int family(int slots, int mode) {
-    constexpr bool has_compact = plan_T(N) >= 64;
+    constexpr bool has_compact = plan_T(N) >= 64, has_lp_compact = plan_T(N) >= 16;
     if (mode == 1 || mode == 2) return mode;
     if (mode == 3) return has_compact ? 3 : 1;
-    if ((long)slots * N * plan_T(N) / 64 <= 1024) return 2;  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
+    if (mode == 4) return has_lp_compact ? 4 : 2;
+    const long waves = (long)slots * N * plan_T(N) / 64;
+    if (waves <= 1024)  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
+        // on the compact intermediate from 256 waves up: 512^2 x 4 30.5 -> 27.7 us, 256^2 x 4 17.8 -> 15.6, 1024^2 x 1 32.1 -> 31.3; 256^2 x 1 loses (11.2 -> 11.5)
+        return (has_lp_compact && waves >= 256) ? 4 : 2;
     return has_compact ? kAutoLargeFamily : 1;
 }
 template <int N>
@@ -35,6 +40,12 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
     if (fam == 2) {
         launch(k_pass1_lp<N>, dim3(blocks, kLayers), dim3(plan_wg_threads(N)), s, lt, buf, args);
         return hipGetLastError();
+    }
+    if constexpr (plan_T(N) >= 16) {
+        if (fam == 4) {
+            launch(k_pass1c_lp<N>, dim3(blocks, 6), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            return hipGetLastError();
+        }
     }
     if constexpr (plan_T(N) >= 64) {
         if (fam == 3) {
@@ -48,8 +59,15 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
 template <int N>
 static hipError_t launch2(int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     const int fam = family<N>(slots, mode);
-    if (fam == 2) {
+    if (fam == 2 || fam == 4) {
         const int lp_blocks = slots * (N / plan_lp_rows(N));
+        if constexpr (plan_T(N) >= 16) {
+            if (fam == 4) {
+                if (buf.f32) launch(k_pass2c_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
+                else launch(k_pass2c_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
+                return hipGetLastError();
+            }
+        }
         if (buf.f32) launch(k_pass2_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
         else launch(k_pass2_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
         return hipGetLastError();

@@ -663,4 +663,139 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
 }
 
+// ===================================================================================================
+// LAYER-PARALLEL + COMPACT INTERMEDIATE (N >= 256): the small-batch kernels on the two-and-a-half-layer intermediate.
+// Pass 1: grid (rows/8, 6); y = 0..2 the compact layers (lower-half blocks of layer 1 leave at once), y = 3..5 the three extra
+// transforms of texel row 0 (only the block that owns row 0 stays).  Pass 2: the four lane groups of a row compute F0..F3.
+// ===================================================================================================
+template <int N, int AUX_T = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP;
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const int L = blockIdx.y;                 // 0..2: layer, 3..5: row-0 transform Q = L - 2
+    if (L == 1 && row0 < N / 2) return;       // hz of the lower rows is the conjugate of the mirrored rows': not transformed
+    if (L >= 3 && row0 != 0) return;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, rw, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, kWgRows);
+    const CascadeFrame cf = args.c[slot];
+    const int y = row0 + rw;
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    cplx h[P];
+    Pass1<N>::load_modulate(h, t, y, h0_c, om_c, cf.time);
+    load_twiddles<N>(tw_lds, buf.tw);
+    const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    const float ky = (float)(y - N / 2) * dky;
+    float ik[P];
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    if (L == 0 && t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
+    cplx d[P];
+    OW_SCHED_FENCE();
+    switch (L) {  // block-uniform
+        case 0: Pass1<N>::template layer_input_c<0>(d, h, ik, t, ky, dkx); break;
+        case 1: Pass1<N>::template layer_input_c<1>(d, h, ik, t, ky, dkx); break;
+        case 2: Pass1<N>::template layer_input_c<2>(d, h, ik, t, ky, dkx); break;
+        case 3: Pass1<N>::template row0_input<1>(d, h, ik, t, ky, dkx); break;
+        case 4: Pass1<N>::template row0_input<2>(d, h, ik, t, ky, dkx); break;
+        default: Pass1<N>::template row0_input<3>(d, h, ik, t, ky, dkx); break;
+    }
+    OW_SCHED_FENCE();
+    row_ifft<N>(d, t, lds_row, tw_lds, rs);
+    if (L >= 3) {  // straight to the side buffer, lanes of row 0 only (the other rows of the block computed nothing of use)
+        if (y == 0) {
+#pragma unroll
+            for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)(L - 2) * 8u, d[OutMap<N>::slot_of(o)]);
+        }
+        return;
+    }
+    rs.sync();
+    Pass1<N>::stage_write(d, t, lds_row);
+    lds_barrier();
+    Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+}
+
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
+__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + plan_sync_flag_cplx(N, plan_lp_rows(N) * kLayers)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);  // which of F0..F3 this lane group transforms (wave-uniform)
+    const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
+    const uint32_t plane = (uint32_t)N * N;
+    constexpr int BPC = N / ROWS;
+    const int slot = blockIdx.x / BPC, row0 = (blockIdx.x % BPC) * ROWS;
+    const CascadeFrame cf = args.c[slot];
+    const int xp = row0 + r;
+    const uint32_t tex = (uint32_t)(xp * N + t);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
+    const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
+    const float dky = (2.0f * kPi) / cf.tile_y;
+    auto region = [&](int row, int layer) { return rows_lds + (layer * ROWS + row) * plan_region_cplx(N); };
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
+    init_row_sync<N>(sync_flags, ROWS * kLayers);
+
+    cplx d[P];
+    switch (g) {  // group-uniform
+        case 0: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 0, T_c); break;
+        case 1:
+            Pass2<N>::template load_layer<AUX_T>(d, t, xp, 0, T_c);
+            Pass2<N>::derive_dx(d, t, xp, dky, pcol_c);
+            break;
+        case 2: Pass2<N>::template load_c1<AUX_T>(d, t, xp, dky, T_c); break;
+        default: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 2, T_c); break;
+    }
+    if (g != 0) Pass2<N>::put_row0(d, t, gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
+    const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
+    load_twiddles<N>(tw_lds, buf.tw);
+    row_ifft<N>(d, t, region(r, g), tw_lds, rs);
+    rs.sync();
+    {
+        cplx *mine = region(r, g);
+#pragma unroll
+        for (int o = 0; o < P; ++o) mine[t + Tn * o] = d[OutMap<N>::slot_of(o)];
+    }
+    lds_barrier();
+    const float fb0 = foam_bits.x, fb1 = foam_bits.y;
+    const uint32_t fpk[2] = {__builtin_bit_cast(uint32_t, fb0), __builtin_bit_cast(uint32_t, fb1)};
+    uint32_t fnew[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = 4 * g + q;  // group-uniform
+        const int e = t + Tn * o;
+        const cplx f0 = lds_read(region(r, 0) + e), f1 = lds_read(region(r, 1) + e), f2 = lds_read(region(r, 2) + e), f3 = lds_read(region(r, 3) + e);
+        // back to the reference's packing: (hx, hy), (hz, dhy_dx), (dhy_dz, dhx_dx), (dhz_dz, dhz_dx)
+        const cplx l1 = cplx{f2.x, f1.y}, l2 = cplx{f3.x, f1.x}, l3 = cplx{f3.y, f2.y};
+        const uint16_t prev = (uint16_t)((fpk[q / 2] >> (16 * (q & 1))) & 0xFFFFu);
+        const uint32_t fh = Pass2<N>::template unpack_texel<F32, AUX_O>(f0, l1, l2, l3, prev, t, xp, o, tex, cf, disp_c, norm_c, f32_c);
+        fnew[q / 2] |= fh << (16 * (q & 1));
+    }
+    const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
+    gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
+}
+
+
 }  // namespace ow

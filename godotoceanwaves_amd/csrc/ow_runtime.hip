@@ -246,7 +246,10 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->layers = cfg->num_cascades < 2 ? 2 : cfg->num_cascades;  // init_gpu(maxi(2, n)), water.gd:91
     c->device = dev;
     c->depth = cfg->depth > 0.0f ? cfg->depth : 20.0f;  // DEPTH, wave_generator.gd:6
-    c->kernel_mode = (cfg->flags & OW_FLAG_KERNELS_STANDARD) ? 1 : (cfg->flags & OW_FLAG_KERNELS_LAYER_PARALLEL) ? 2 : (cfg->flags & OW_FLAG_KERNELS_COMPACT) ? 3 : 0;
+    {
+        const bool lp = cfg->flags & OW_FLAG_KERNELS_LAYER_PARALLEL, cp = cfg->flags & OW_FLAG_KERNELS_COMPACT;
+        c->kernel_mode = (cfg->flags & OW_FLAG_KERNELS_STANDARD) ? 1 : (lp && cp) ? 4 : lp ? 2 : cp ? 3 : 0;
+    }
 
     auto bail = [&](ow_status st) {
         ow_destroy(c);
@@ -560,7 +563,7 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     std::vector<ow::cplx> t(pl * ow::kLayers);
     if (c->slot_of[cascade] < 0)
         return fail(OW_ERR_STATE, "cascade %d was not part of the most recent batch: its intermediate has been overwritten", cascade);
-    if (c->last_family == 3)
+    if (c->last_family >= 3)
         return fail(OW_ERR_STATE, "the most recent batch used the compact (three-layer) intermediate, which has no counterpart in the "
                                   "reference's fft_buffer: create the context with OW_FLAG_KERNELS_STANDARD to inspect it");
     OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + (size_t)c->slot_of[cascade] * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));

@@ -125,7 +125,8 @@ class WaveGenerator:
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
                         normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) |
                         {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL,
-                               "compact": OW_FLAG_KERNELS_COMPACT}[self.kernels])
+                               "compact": OW_FLAG_KERNELS_COMPACT,
+                               "layer_parallel_compact": OW_FLAG_KERNELS_LAYER_PARALLEL | OW_FLAG_KERNELS_COMPACT}[self.kernels])
         ctx = C.c_void_p()
         _lib.check(self._lib.ow_create(C.byref(cfg), C.byref(ctx)))
         self.context = ctx
@@ -261,7 +262,7 @@ class WaveGenerator:
         _lib.check(self._lib.ow_get_intermediate(self.context, cascade, out.ctypes.data))
         return out
 
-    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact"}
+    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact", 4: "layer_parallel_compact"}
 
     def last_kernel_family(self):
         """which kernels the most recent batch ran with: "standard", "layer_parallel", "compact" (None before the first launch)"""

@@ -80,8 +80,9 @@ typedef struct ow_config {
  * packing) elsewhere.  These flags pin the choice (tests, measurements). */
 #define OW_FLAG_KERNELS_STANDARD 2u
 #define OW_FLAG_KERNELS_LAYER_PARALLEL 4u
-/* Compact-intermediate kernels (map_size >= 1024; standard ones below that): three packed layers cross the
- * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them. */
+/* Compact-intermediate kernels (map_size >= 1024; standard ones below that): two and a half packed layers cross the
+ * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them.
+ * Together with OW_FLAG_KERNELS_LAYER_PARALLEL: the layer-parallel kernels on the compact intermediate (map_size >= 256). */
 #define OW_FLAG_KERNELS_COMPACT 8u
 
 typedef struct ow_context ow_context;
@@ -209,7 +210,8 @@ ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
 
 /* Kernel family the most recent batch was launched with: 1 = standard (k_pass1 / k_pass2), 2 = layer-parallel
- * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c); 0 before the first launch. */
+ * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c), 4 = layer-parallel on the compact intermediate (k_pass1c_lp /
+ * k_pass2c_lp); 0 before the first launch. */
 int32_t ow_last_kernel_family(const ow_context *ctx);
 
 /* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
