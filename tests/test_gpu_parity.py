@@ -299,3 +299,26 @@ def test_compact_kernels_on_parameter_range_edges(names):
                 assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (names[i], cname)
             elif np.abs(ref[..., c]).max() > 0:
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (names[i], cname, H.relmax(f32[..., c], ref[..., c]))
+
+
+@pytest.mark.parametrize("n,ids,family", [(1024, [0, 1, 2], "compact"), (512, [0, 1, 2, 3, 4, 5, 6, 7], "standard"),
+                                          (256, [0, 1, 2, 3, 4, 5, 6, 7], "layer_parallel_compact"), (128, [0, 1, 2, 3, 4, 5, 6, 7], "layer_parallel"),
+                                          (2048, [1], "compact")])
+def test_runtime_kernel_choice_and_parity(n, ids, family):
+    """what the runtime picks on its own for odd cascade counts and sizes, and that each choice matches the oracle (two frames)"""
+    gen, params = make_gen(n, ids)
+    og = H.oracle_generator(n, ids)
+    for _ in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == family
+    for i in range(len(ids)):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
