@@ -1,0 +1,89 @@
+/* c_consumer.c -- the C-ABI used from plain C, the way a GDExtension / C# shim would: create a context, drive it with the
+ * reference's schedule (WaveGenerator.update + one cascade per rendered frame, wave_generator.gd:56-63,90-109), hand every
+ * finished layer to the host asynchronously (what RenderingDevice.texture_update would consume), sample the surface on the
+ * device, and print checksums.
+ *   gcc -O2 -std=c99 -Iinclude examples/c_consumer.c -o c_consumer -Lgodotoceanwaves_amd -locean_waves \
+ *       -Wl,-rpath,$PWD/godotoceanwaves_amd -Wl,-rpath-link,/opt/rocm/lib -lm && ./c_consumer [map_size [frames]] */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ocean_waves.h"
+
+static uint64_t fnv1a(const void *data, size_t n) {
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 256, cascades = 3, frames = argc > 2 ? atoi(argv[2]) : 12;
+
+    ow_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.map_size = n; cfg.num_cascades = cascades; cfg.device_id = -1; cfg.depth = 20.0f;
+    ow_context *ctx = NULL;
+    if (ow_create(&cfg, &ctx) != OW_OK) { fprintf(stderr, "ow_create: %s\n", ow_last_error()); return 1; }
+
+    /* the three cascades of the reference's main.tscn, seeds and time offsets as water.gd:31-32 assigns them */
+    static const float tile[3] = {88.0f, 57.0f, 16.0f}, wind[3] = {10.0f, 5.0f, 20.0f}, dir[3] = {20.0f, 15.0f, 20.0f};
+    static const float fetch[3] = {150.0f, 150.0f, 550.0f}, spread[3] = {0.2f, 0.4f, 0.4f}, whitecap[3] = {0.5f, 0.5f, 0.25f}, foam[3] = {8.0f, 0.0f, 3.0f};
+    ow_cascade_params par[3];
+    float map_scales[3][4];
+    for (int i = 0; i < cascades; ++i) {
+        ow_cascade_params_default(&par[i]);
+        par[i].tile_length[0] = par[i].tile_length[1] = tile[i];
+        par[i].wind_speed = wind[i]; par[i].wind_direction = dir[i]; par[i].fetch_length = fetch[i];
+        par[i].spread = spread[i]; par[i].whitecap = whitecap[i]; par[i].foam_amount = foam[i];
+        par[i].spectrum_seed[0] = 1000 + 17 * i; par[i].spectrum_seed[1] = -2000 + 31 * i;
+        par[i].time = 120.0 + 3.14159265358979323846 * i;
+        map_scales[i][0] = map_scales[i][1] = 1.0f / tile[i];   /* water.gd:105-109 */
+        map_scales[i][2] = par[i].displacement_scale; map_scales[i][3] = par[i].normal_scale;
+    }
+
+    uint64_t sum = 0;
+    int in_flight = -1, handed = 0;
+    for (int f = 0; f < frames; ++f) {
+        if (ow_cascades_remaining(ctx) == 0 && ow_update(ctx, 1.0 / 50.0, par, cascades) != OW_OK) goto fail;   /* water.gd:114 */
+        if (in_flight >= 0) {   /* the layer computed last frame has crossed PCIe meanwhile */
+            const void *d, *m;
+            if (ow_readback_wait(ctx, in_flight, &d, &m) != OW_OK) goto fail;
+            sum ^= fnv1a(d, (size_t)n * n * 8) + 31 * fnv1a(m, (size_t)n * n * 8) + (uint64_t)in_flight;
+            ++handed;
+        }
+        const int layer = ow_cascades_remaining(ctx) - 1;
+        if (ow_process(ctx) != OW_OK) goto fail;                               /* wave_generator.gd:56-63: one cascade per frame */
+        if (ow_readback_begin(ctx, 1u << layer) != OW_OK) goto fail;
+        in_flight = layer;
+    }
+    {
+        const void *d, *m;
+        if (ow_readback_wait(ctx, in_flight, &d, &m) != OW_OK) goto fail;
+        sum ^= fnv1a(d, (size_t)n * n * 8) + 31 * fnv1a(m, (size_t)n * n * 8) + (uint64_t)in_flight;
+        ++handed;
+    }
+    {   /* what the water / sea-spray shaders would read along a line of 64 world points */
+        float xz[64][2];
+        ow_surface_sample s[64];
+        for (int i = 0; i < 64; ++i) { xz[i][0] = -40.0f + 1.25f * i; xz[i][1] = 7.5f + 0.5f * i; }
+        if (ow_sample_surface(ctx, &xz[0][0], 64, &map_scales[0][0], cascades, s) != OW_OK) goto fail;
+        double hmin = 1e9, hmax = -1e9;
+        int active = 0;
+        for (int i = 0; i < 64; ++i) {
+            if (s[i].displacement[1] < hmin) hmin = s[i].displacement[1];
+            if (s[i].displacement[1] > hmax) hmax = s[i].displacement[1];
+            active += s[i].spray_active;
+        }
+        printf("layers_handed_off=%d checksum=%016llx wave_height=[%.4f,%.4f] spray_active=%d\n", handed, (unsigned long long)sum, hmin, hmax, active);
+        if (!(hmax > hmin) || !isfinite(hmin) || !isfinite(hmax)) { fprintf(stderr, "flat or non-finite surface\n"); ow_destroy(ctx); return 1; }
+    }
+    ow_destroy(ctx);
+    return 0;
+fail:
+    fprintf(stderr, "ocean_waves: %s\n", ow_last_error());
+    ow_destroy(ctx);
+    return 1;
+}
