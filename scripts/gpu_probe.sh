@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_c_consumer.py -q 2>&1 | tail -8
+timeout 300 python scripts/two_ctx.py 1024 2>&1 | tail -12
