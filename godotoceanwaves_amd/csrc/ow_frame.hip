@@ -49,7 +49,7 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
     }
     if constexpr (plan_T(N) >= 64) {
         if (fam == 3) {
-            launch(k_pass1c<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            launch(k_pass1c<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, (Stamp *)nullptr);
             return hipGetLastError();
         }
     }

@@ -377,8 +377,17 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 // layers cross T instead of four (24 instead of 32 B/texel each way): see Pass1::layer_input_c / Pass2::derive_dx in
 // ow_device.h and tests/test_compact_math.py for the algebra.  Same structure as k_pass1 / k_pass2 otherwise.
 // ===================================================================================================
-template <int N, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
-__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(DeviceBuffers buf, FrameArgs args) {
+// STAMPS (tools/kbench only): per-wave cycle stamps at the phase boundaries, written to `stamps`
+template <int N, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+    unsigned long long ts[STAMPS ? 16 : 1] = {0};
+    auto stamp = [&](int k, float keep) {
+        if constexpr (STAMPS) {
+            asm volatile("" ::"v"(keep));
+            ts[k] = __builtin_readcyclecounter();
+        }
+    };
+    stamp(0, 0.0f);
     constexpr int Tn = plan_T(N), P = kP, LC = Pass1<N>::kCompactLayers;
     static_assert(Tn >= 64, "a wave must not mix rows");
     __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
 
     cplx h[P];
     Pass1<N>::template load_modulate<AUX_H>(h, t, y, h0_c, om_c, cf.time);
+    stamp(1, h[0].x);
     load_twiddles<N>(tw_lds, buf.tw);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
@@ -454,12 +464,27 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
             if (L == 2) Pass1<N>::template layer_input_c<2>(d, h, ik, to, kyo, dkxo, drain);
         }
         OW_SCHED_FENCE();
+        stamp(2 + 3 * L, d[0].x);
         if (L > 0) row_ifft<N, true>(d, t, lds_row, tw_lds, rs);
         else row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
+        stamp(3 + 3 * L, d[0].x);
         rs.sync();
         Pass1<N>::stage_write(d, t, lds_row);
         lds_barrier();
         if (L == LC - 1) Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+        stamp(4 + 3 * L, d[0].x);
+    }
+    if constexpr (STAMPS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[14] = __builtin_readcyclecounter();
+        ts[15] = (unsigned long long)row0;
+        if ((threadIdx.x & 63) == 0) {
+            Stamp st;
+            for (int k = 0; k < 16; ++k) st.t[k] = ts[k];
+            st.xcc = xcc_id();
+            st.pad = 0;
+            stamps[blockIdx.x * ((plan_wg_threads(N) + 63) / 64) + threadIdx.x / 64] = st;
+        }
     }
 }
 

@@ -102,5 +102,24 @@ int main(int argc, char **argv) {
         printf("pass1 phase stamps (kcycles since first wave start; delta):\n");
         for (int k = 0; k < 15; ++k) printf("  %-10s %8.2f  (+%.2f)\n", names[k], avg[k] / 1e3, k ? (avg[k] - avg[k - 1]) / 1e3 : 0.0);
     }
+    {   // compact pass 1: per-phase averages, upper-half and lower-half blocks apart (the kernel needs the side buffers)
+        CK(hipMalloc((void**)&buf.pcol, (size_t)C * N * 8)); CK(hipMalloc((void**)&buf.rrow, (size_t)C * N * 32));
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_pass1c<N, kAuxDefault, kAuxDefault, true>), dim3(blocks1), dim3(thr1), 0, s, buf, args, st);
+        CK(hipStreamSynchronize(s));
+        const int waves = C * N * plan_T(N) / 64; std::vector<Stamp> h(waves); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * waves, hipMemcpyDeviceToHost));
+        const char *names[15] = {"start", "modulated", "C0 input", "C0 fft", "C0 staged", "C1 input", "C1 fft", "C1 staged", "C2 input", "C2 fft", "C2 staged(+stores issued)", "", "", "", "drained"};
+        for (int half = 0; half < 2; ++half) {  // half 0: upper blocks (rows >= N/2, three transforms), half 1: lower blocks (two)
+            double avg[15] = {0}; int cnt = 0;
+            for (auto &x : h) {
+                const bool lower = (int)x.t[15] < N / 2;
+                if ((int)lower != half) continue;
+                for (int k = 0; k < 15; ++k) avg[k] += x.t[k] ? (double)(x.t[k] - x.t[0]) : 0.0;  // since this wave's own start
+                ++cnt;
+            }
+            printf("k_pass1c phases, %s blocks (%d waves): average time since the wave's start, in ticks of the shader clock counter\n", half ? "lower (2 transforms)" : "upper (3 transforms)", cnt);
+            double prev = 0;
+            for (int k = 1; k < 15; ++k) if (names[k][0] && avg[k] > 0) { printf("  %-28s %9.1f  (+%.1f)\n", names[k], avg[k] / cnt, avg[k] / cnt - prev); prev = avg[k] / cnt; }
+        }
+    }
     return 0;
 }
