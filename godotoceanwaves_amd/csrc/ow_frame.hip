@@ -24,14 +24,16 @@ bool supported_map_size(int n) { return n == 128 || n == 256 || n == 512 || n ==
 // and run at one wave's serial latency.
 template <int N>
 static int family(int slots, int mode) {
-    constexpr bool has_compact = plan_T(N) >= 64, has_lp_compact = plan_T(N) >= 16;
+    constexpr bool has_compact = plan_T(N) >= 16, has_lp_compact = plan_T(N) >= 16;
     if (mode == 1 || mode == 2) return mode;
     if (mode == 3) return has_compact ? 3 : 1;
     if (mode == 4) return has_lp_compact ? 4 : 2;
     const long waves = (long)slots * N * plan_T(N) / 64;
-    if (waves <= 1024)  // measured crossover (scripts/mode_bench.py): 1024^2 x 1, 512^2 x 4 gain, 1024^2 x 2, 512^2 x 8 lose
-        // on the compact intermediate from 256 waves up: 512^2 x 4 30.5 -> 27.7 us, 256^2 x 4 17.8 -> 15.6, 1024^2 x 1 32.1 -> 31.3; 256^2 x 1 loses (11.2 -> 11.5)
-        return (has_lp_compact && waves >= 256) ? 4 : 2;
+    // measured crossovers (scripts/mode_bench.py).  Four-layer kernels (N = 128): layer-parallel up to 1024 waves.  Compact
+    // intermediate: layer-parallel from 256 waves (256^2 x 1 loses 3 % and stays on the four-layer pair) up to 1280
+    // (512^2 x 5: 32.8 vs 35.9 us; 512^2 x 6: 36.1 vs 35.2; 1024^2 x 2: 48.3 vs 39.3).
+    if (has_lp_compact && waves >= 256 && waves <= 1280) return 4;
+    if (waves <= 1024) return 2;
     return has_compact ? kAutoLargeFamily : 1;
 }
 template <int N>
@@ -47,7 +49,7 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
             return hipGetLastError();
         }
     }
-    if constexpr (plan_T(N) >= 64) {
+    if constexpr (plan_T(N) >= 16) {
         if (fam == 3) {
             launch(k_pass1c<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, (Stamp *)nullptr);
             return hipGetLastError();
@@ -73,7 +75,7 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
         return hipGetLastError();
     }
     const int blocks = slots * (N / kWgRows);
-    if constexpr (plan_T(N) >= 64) {
+    if constexpr (plan_T(N) >= 16) {
         if (fam == 3) {
             if (buf.f32) launch(k_pass2c<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
             else launch(k_pass2c<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 
 
 // ===================================================================================================
-// COMPACT-INTERMEDIATE variants of the two standard kernels (N >= 1024: a wave carries whole rows).  Three packed
+// COMPACT-INTERMEDIATE variants of the two standard kernels (N >= 256).  Three packed
 // layers cross T instead of four (24 instead of 32 B/texel each way): see Pass1::layer_input_c / Pass2::derive_dx in
 // ow_device.h and tests/test_compact_math.py for the algebra.  Same structure as k_pass1 / k_pass2 otherwise.
 // ===================================================================================================
@@ -389,12 +389,12 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     };
     stamp(0, 0.0f);
     constexpr int Tn = plan_T(N), P = kP, LC = Pass1<N>::kCompactLayers;
-    static_assert(Tn >= 64, "a wave must not mix rows");
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
     __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
-    const int rw = __builtin_amdgcn_readfirstlane(tau / Tn), t = tau % Tn;
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
@@ -422,7 +422,9 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     Pass1<N>::wave_numbers(ik, t, ky, dkx);
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
-    if (y == 0) {  // wave-uniform, one row per cascade: the three extra transforms of texel row 0, straight to the side buffer
+    // the wave that holds texel row 0 (its first lane does; for N < 1024 it holds a few more rows, transformed along and
+    // discarded) does the three extra transforms of that row, straight to the side buffer
+    if (__builtin_amdgcn_readfirstlane(y) == 0) {
 #pragma unroll
         for (int Q = 1; Q <= 3; ++Q) {
             cplx d[P];
@@ -439,8 +441,10 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
             OW_SCHED_FENCE();
             row_ifft<N, false>(d, t, lds_row, tw_lds, rs);
             rs.sync();  // the row region is free again before the next transform writes into it
+            if (y == 0) {
 #pragma unroll
-            for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)Q * 8u, d[OutMap<N>::slot_of(o)]);
+                for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)Q * 8u, d[OutMap<N>::slot_of(o)]);
+            }
         }
     }
 
@@ -491,12 +495,12 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
 template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers buf, FrameArgs args) {
     constexpr int Tn = plan_T(N), P = kP;
-    static_assert(Tn >= 64, "a wave must not mix rows");
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
     __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
-    const int rw = __builtin_amdgcn_readfirstlane(tau / Tn), t = tau % Tn;
+    const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));

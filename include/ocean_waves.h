@@ -76,11 +76,11 @@ typedef struct ow_config {
 #define OW_FLAG_DEBUG_F32 1u /* also keep 8 pre-quantisation FP32 channels per texel (parity tests) */
 /* Kernel family.  By default the runtime picks per batch: the layer-parallel kernels (one lane group per row AND
  * packed layer) when a batch is too small to fill the chip; otherwise the compact-intermediate kernels where they
- * exist (map_size >= 1024) and the standard ones (one lane group per row, four layers in sequence, the reference's
+ * exist (map_size >= 256) and the standard ones (one lane group per row, four layers in sequence, the reference's
  * packing) elsewhere.  These flags pin the choice (tests, measurements). */
 #define OW_FLAG_KERNELS_STANDARD 2u
 #define OW_FLAG_KERNELS_LAYER_PARALLEL 4u
-/* Compact-intermediate kernels (map_size >= 1024; standard ones below that): two and a half packed layers cross the
+/* Compact-intermediate kernels (map_size >= 256; standard ones below that): two and a half packed layers cross the
  * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them.
  * Together with OW_FLAG_KERNELS_LAYER_PARALLEL: the layer-parallel kernels on the compact intermediate (map_size >= 256). */
 #define OW_FLAG_KERNELS_COMPACT 8u

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 200 ./tools/kbench 4 30 > gpurun_out/kbench.log 2>&1; grep -A14 "k_pass1c phase" gpurun_out/kbench.log
+timeout 800 python -m pytest tests -m gpu -q 2>&1 | tail -4
+timeout 300 python scripts/mode_bench.py 2>&1 | tee gpurun_out/mode_bench.log | grep -E "None"

@@ -4,7 +4,7 @@ in-situ per-kernel durations.  Usage: python scripts/mode_bench.py [n:c ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
-cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(2048, 1), (2048, 4), (1024, 1), (1024, 2), (1024, 4), (512, 1), (512, 4), (256, 1), (256, 4), (128, 4)]
+cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(2048, 1), (2048, 4), (1024, 1), (1024, 2), (1024, 4), (512, 1), (512, 4), (512, 8), (256, 1), (256, 4), (128, 4)]
 for n, c in cases:
     for mode in (None, "standard", "layer_parallel", "compact", "layer_parallel_compact"):
         gen = WaveGenerator(); gen.map_size = n; gen.kernels = mode; gen.init_gpu(max(2, c))
