@@ -1,4 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 800 python -m pytest tests -m gpu -q 2>&1 | tail -4
-timeout 300 python scripts/mode_bench.py 2>&1 | tee gpurun_out/mode_bench.log | grep -E "None"
+V=$GRAFT_REPO_ROOT/godotoceanwaves_amd/csrc/build/variants
+echo "== no delay"; timeout 300 python scripts/mode_bench.py 1024:4 2048:1 2>&1 | grep -E "None"
+for d in 2 4 6 8; do echo "== lower blocks delayed by ~$d us"; OCEAN_WAVES_LIB=$V/delay$d.so timeout 300 python scripts/mode_bench.py 1024:4 2048:1 2>&1 | grep -E "None"; done
+echo "== no delay"; timeout 300 python scripts/mode_bench.py 1024:4 2048:1 2>&1 | grep -E "None"
