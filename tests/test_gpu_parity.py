@@ -322,3 +322,40 @@ def test_runtime_kernel_choice_and_parity(n, ids, family):
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
         disp, norm = gen.get_maps(i)
         assert H.quantisation_exact(f32, disp, norm)
+
+
+def test_live_parameter_edits_between_ticks_compact_family():
+    """the reference's UI edits parameters while the simulation runs (wave_cascade_parameters.gd setters raise the dirty flag):
+    a spectrum regeneration and a non-spectrum edit between ticks, on the runtime's default kernels at 1024^2 x 2, with a
+    non-default depth"""
+    n, ids = 1024, [0, 2]
+    gen = WaveGenerator()
+    gen.map_size, gen.debug_f32, gen.depth = n, True, 35.0
+    gen.init_gpu(2)
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    og = O.Generator(n, 2, 35.0)
+    for i, ci in enumerate(ids):
+        H.set_params(og.params[i], cascade_preset(ci))
+    for frame in range(4):
+        if frame == 2:
+            params[0].wind_speed = 14.0          # regenerates cascade 0's spectrum on the next update
+            params[1].tile_length = (21.0, 34.0)
+            og.params[0].wind_speed = 14.0
+            og.params[0].should_generate_spectrum = 1
+            og.params[1].tile_length[0], og.params[1].tile_length[1] = 21.0, 34.0
+            og.params[1].should_generate_spectrum = 1
+        if frame == 3:
+            params[1].foam_amount = 2.5           # the reference regenerates on this one too (wave_cascade_parameters.gd:32-35)
+            og.params[1].foam_amount = 2.5
+            og.params[1].should_generate_spectrum = 1
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == "compact"
+    for i in range(2):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name, H.relmax(f32[..., c], ref[..., c]))
