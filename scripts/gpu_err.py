@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers as H
 from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
-for n, ids in [(256, [0, 1, 2, 3]), (512, [2, 4]), (1024, [2])]:
+for n, ids in [(256, [0, 1, 2, 3]), (512, [2, 4]), (1024, [2]), (1024, [0, 1, 2, 3]), (2048, [1])]:
     gen = WaveGenerator(); gen.map_size = n; gen.debug_f32 = True; gen.init_gpu(max(2, len(ids)))
     params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
     og = H.oracle_generator(n, ids)
@@ -16,4 +16,4 @@ for n, ids in [(256, [0, 1, 2, 3]), (512, [2, 4]), (1024, [2])]:
         f32, ref = gen.get_maps_f32(i), og.f32(i)
         errs = " ".join(f"{name}:{H.relmax(f32[..., c], ref[..., c]):.1e}" for c, name in enumerate(H.CHANNELS) if name != "foam")
         disp, norm = gen.get_maps(i)
-        print(n, ids[i], errs, "fp16 disp %.2f norm %.2f" % (H.fp16_close(disp, og.displacement(i)), H.fp16_close(norm[..., :3], og.normal(i)[..., :3])))
+        print(n, ids[i], gen.last_kernel_family(), errs, "fp16 disp %.2f norm %.2f" % (H.fp16_close(disp, og.displacement(i)), H.fp16_close(norm[..., :3], og.normal(i)[..., :3])))
