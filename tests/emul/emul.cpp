@@ -84,8 +84,57 @@ void rows_fft(const float *in, float *out, int rows) {
     }
 }
 
+// Pass 2 of the layer-parallel kernels (k_pass2_lp / k_pass2c_lp): the four transforms of a row are done by four lane groups, left
+// in natural order, and every texel is finished by Pass2::unpack_texel from the four values.  `compact`: the groups compute
+// F0..F3 from the compact intermediate and the combine step maps them back to the reference's packing.  Pass 1 must have
+// run before (frame<N> or frame_compact<N> up to the end of its pass 1): here T / the side buffers are inputs.
 template <int N>
-void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
+void pass2_lp(bool compact, CascadeFrame cf, const float *Tbuf, const cplx *pcol, const cplx *rrow, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
+    constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
+    const float dky = (2.0f * kPi) / cf.tile_y;
+    const uint32_t plane = (uint32_t)N * N;
+    const GBuf T_c = make_gbuf(Tbuf, t_cascade_bytes(N)), pcol_c = make_gbuf(pcol, (uint32_t)N * 8u), rrow_c = make_gbuf(rrow, (uint32_t)N * 32u);
+    const GBuf disp_c = make_gbuf(disp, plane * 8u), norm_c = make_gbuf(norm, plane * 8u), foam_c = make_gbuf(foam, plane * 2u), f32_c = make_gbuf(f32, plane * 32u);
+    Block<N, NT> w;
+    static cplx f[4][NT][P];
+    std::vector<cplx> nat((size_t)4 * NT * P);  // [group][thread][o]: the LDS regions in natural order
+    for (int row0 = 0; row0 < N; row0 += kWgRows) {
+        auto xp_of = [&](int l) { return row0 + l / Tn; };
+        for (int g = 0; g < 4; ++g) {
+            for (int l = 0; l < NT; ++l) {
+                const int t = l % Tn, xp = xp_of(l);
+                if (!compact) {
+                    Pass2<N>::template load_layer<0>(f[g][l], t, xp, g, T_c);
+                } else if constexpr (Tn >= 16) {
+                    if (g == 0) Pass2<N>::template load_layer<0>(f[g][l], t, xp, 0, T_c);
+                    if (g == 1) { Pass2<N>::template load_layer<0>(f[g][l], t, xp, 0, T_c); Pass2<N>::derive_dx(f[g][l], t, xp, dky, pcol_c); }
+                    if (g == 2) Pass2<N>::template load_c1<0>(f[g][l], t, xp, dky, T_c);
+                    if (g == 3) Pass2<N>::template load_layer<0>(f[g][l], t, xp, 2, T_c);
+                    if (g != 0) Pass2<N>::put_row0(f[g][l], t, gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
+                }
+            }
+            w.row_ifft(f[g]);
+            for (int l = 0; l < NT; ++l)
+                for (int o = 0; o < P; ++o) nat[((size_t)g * NT + l) * P + o] = f[g][l][OutMap<N>::slot_of(o)];
+        }
+        for (int l = 0; l < NT; ++l) {
+            const int t = l % Tn, xp = xp_of(l);
+            const uint32_t tex = (uint32_t)(xp * N + t);
+            for (int o = 0; o < P; ++o) {
+                const cplx a = nat[((size_t)0 * NT + l) * P + o], b = nat[((size_t)1 * NT + l) * P + o], c = nat[((size_t)2 * NT + l) * P + o], d = nat[((size_t)3 * NT + l) * P + o];
+                cplx l0 = a, l1 = b, l2 = c, l3 = d;
+                if (compact) { l1 = cplx{c.x, b.y}; l2 = cplx{d.x, b.x}; l3 = cplx{d.y, c.y}; }
+                uint16_t *fp = foam + Pass2<N>::foam_index(xp, t) + o;
+                const uint16_t prev = *fp;
+                *fp = f32 ? Pass2<N>::template unpack_texel<true, 0>(l0, l1, l2, l3, prev, t, xp, o, tex, cf, disp_c, norm_c, f32_c)
+                          : Pass2<N>::template unpack_texel<false, 0>(l0, l1, l2, l3, prev, t, xp, o, tex, cf, disp_c, norm_c, f32_c);
+            }
+        }
+    }
+}
+
+template <int N>
+void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32, bool lp = false) {
     constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const uint32_t plane = (uint32_t)N * N;
@@ -118,6 +167,10 @@ void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, u
                 // lds_barrier()
             }
         }
+    }
+    if (lp) {  // k_pass1_lp computes the same rows with the same lane code, one layer per block: T is what pass 1 above left
+        pass2_lp<N>(false, cf, Tbuf, nullptr, nullptr, disp, norm, foam, f32);
+        return;
     }
     // ---- pass 2 (mirrors k_pass2: layers 2, 3, 1, 0) ----
     {
@@ -160,7 +213,7 @@ void frame(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, u
 
 // the same frame through the compact (three-layer) intermediate: mirrors k_pass1c / k_pass2c
 template <int N>
-void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32) {
+void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float *Tbuf, uint16_t *disp, uint16_t *norm, uint16_t *foam, float *f32, bool lp = false) {
     constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const uint32_t plane = (uint32_t)N * N;
@@ -204,6 +257,10 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
                 for (int l = 0; l < NT; ++l) Pass1<N>::template stage_store<0>(l, L, row0, w.lds.data(), T_c);
             }
         }
+    }
+    if (lp) {
+        pass2_lp<N>(true, cf, Tbuf, pcol.data(), rrow.data(), disp, norm, foam, f32);
+        return;
     }
     {   // ---- pass 2: F2, F0, F1, F3 ----
         static cplx f[NT][P], c0[NT][P];
@@ -294,6 +351,16 @@ int emul_frame(int n, const float *h0a, const float *omega, const CascadeFrame *
         case 512: frame<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 1024: frame<1024>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
         case 2048: frame<2048>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32); return 0;
+    }
+    return 1;
+}
+
+int emul_frame_lp(int n, int compact, const float *h0a, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,
+                  uint16_t *norm, uint16_t *foam, float *f32) {
+    switch (n) {
+        case 128: if (compact) return 1; frame<128>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32, true); return 0;
+        case 256: if (compact) frame_compact<256>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32, true); else frame<256>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32, true); return 0;
+        case 512: if (compact) frame_compact<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32, true); else frame<512>(h0a, omega, *cf, Tbuf, disp, norm, foam, f32, true); return 0;
     }
     return 1;
 }

@@ -40,6 +40,7 @@ def emul():
     E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p, f32p]
     E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_frame_compact.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
+    E.emul_frame_lp.argtypes = [C.c_int, C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
     return E
 
@@ -66,13 +67,16 @@ def test_row_ifft_is_unnormalised_inverse_dft(emul, n):
     assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 5e-7
 
 
-@pytest.mark.parametrize("intermediate", ["reference_layout", "compact"])
+@pytest.mark.parametrize("intermediate", ["reference_layout", "compact", "reference_layout_lp", "compact_lp"])
 @pytest.mark.parametrize("n,ci", [(128, 0), (256, 2), (512, 1), (128, "non_square_tile"), (128, "late_time")])
 def test_emulated_kernels_match_oracle(emul, n, ci, intermediate):
-    """both kernel families: the four-layer intermediate of the reference and the compact three-layer one
-    (Pass1::layer_input_c, tests/test_compact_math.py)"""
-    frame_fn = emul.emul_frame if intermediate == "reference_layout" else emul.emul_frame_compact
-    if intermediate == "compact" and n < 256:
+    """every kernel family: the four-layer intermediate of the reference and the compact one (Pass1::layer_input_c,
+    tests/test_compact_math.py), each with the standard pass 2 and with the layer-parallel one (four lane groups per row,
+    Pass2::unpack_texel)"""
+    frame_fn = {"reference_layout": emul.emul_frame, "compact": emul.emul_frame_compact,
+                "reference_layout_lp": lambda n_, *a: emul.emul_frame_lp(n_, 0, *a),
+                "compact_lp": lambda n_, *a: emul.emul_frame_lp(n_, 1, *a)}[intermediate]
+    if intermediate.startswith("compact") and n < 256:
         n = 256  # the compact lane code needs N/16 to be a multiple of the 16-row line of T (the kernels exist for N >= 1024 only)
     if isinstance(ci, str):
         from edge_presets import edge_presets
