@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python scripts/gpu_err.py 2>&1 | tee gpurun_out/parity_margins.txt | tail -14
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "long_run" 2>&1 | tail -12

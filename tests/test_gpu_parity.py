@@ -359,3 +359,35 @@ def test_live_parameter_edits_between_ticks_compact_family():
                 assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
             else:
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name, H.relmax(f32[..., c], ref[..., c]))
+
+
+def test_long_run_matches_the_oracle_at_the_final_time():
+    """20 000 ticks of the headline configuration (400 s of simulated time, phases up to ~3e4 rad).  Everything but foam is a
+    function of the time alone, so the oracle can be started one tick before the end: the HIP path, after 20 010 ticks of
+    FP64 `time += delta` on the host (wave_generator.gd:103) and FP32 phases on the device, must still agree with it; foam
+    (recurrent) stays in [0, 1]."""
+    n, ids, ticks = 1024, [0, 1, 2, 3], 20000
+    gen, params = make_gen(n, ids)
+    gen.run(UPDATE_DELTA, params, 10)
+    t_expect = [p.time for p in params]
+    gen.run(UPDATE_DELTA, params, ticks)
+    gen.sync()
+    og = H.oracle_generator(n, ids)
+    for i in range(4):
+        for _ in range(ticks):
+            t_expect[i] += UPDATE_DELTA
+        assert params[i].time == t_expect[i]
+    # one oracle tick ending at the same time: rewind by the delta it is about to add
+    for i in range(4):
+        og.params[i].time = t_expect[i] - UPDATE_DELTA
+    og.update_all(UPDATE_DELTA)
+    for i in range(4):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        assert np.isfinite(f32).all()
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert f32[..., c].min() >= 0.0 and f32[..., c].max() <= 1.0
+            else:
+                # time - delta + delta is not bit for bit the accumulated time: allow the phase of one FP64 ulp at 520 s (nothing)
+                # plus the usual tolerance
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name, H.relmax(f32[..., c], ref[..., c]))
