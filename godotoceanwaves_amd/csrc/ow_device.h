@@ -611,8 +611,10 @@ struct Pass1 {
     // amplitude once per tick (8 + 2 B/texel instead of 16 + 4).
     // a_off / b_off: byte offsets of a[y][t] and of the mirrored texel of (t, slot 0 of the natural order);
     // b_wrap: lane 0 of a row pairs x = 0 with x = 0 (not with x = N).
+    // load_raw issues the loads (a = h0(k), b = the mirrored texel, om = omega); modulate consumes them.  Apart they let a kernel
+    // put other work -- the twiddle table's way into LDS and its barrier -- between issue and first use.
     template <int AUX = 0>
-    static OW_DEV void load_modulate(cplx *h, int t, int y, GBuf h0_c, GBuf om_c, float time) {
+    static OW_DEV void load_raw(cplx *a, cplx *b, float *om, int t, int y, GBuf h0_c, GBuf om_c) {
         const int ym = (N - y) % N;
         const int tm = (T - t) % T;                           // lane part of the mirrored column
         const uint32_t a_off = (uint32_t)(y * N + t) * 8u;
@@ -621,8 +623,6 @@ struct Pass1 {
         // omega: own row for y <= N/2, else the mirrored row (same values, shared lines)
         const bool om_mirror = y > N / 2;
         const uint32_t o_off = (om_mirror ? (uint32_t)(ym * N + tm) : (uint32_t)(y * N + t)) * 4u;
-        cplx a[P], b[P];
-        float om[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int blk = rot(j);  // x = t + T*blk ;  mirrored x = (T - t) + T*(15 - blk)  [t > 0],  T*((16 - blk) % 16)  [t = 0]
@@ -638,6 +638,8 @@ struct Pass1 {
                                   : gload4<AUX>(om_c, o_off, (uint32_t)(T * blk) * 4u);
             }
         }
+    }
+    static OW_DEV void modulate(cplx *h, const cplx *a, const cplx *b, const float *om, float time) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             float sn, cs;
@@ -655,6 +657,13 @@ struct Pass1 {
             opaque_inplace(h[j]);
             if (j % 4 == 3) OW_SCHED_FENCE();
         }
+    }
+    template <int AUX = 0>
+    static OW_DEV void load_modulate(cplx *h, int t, int y, GBuf h0_c, GBuf om_c, float time) {
+        cplx a[P], b[P];
+        float om[P];
+        load_raw<AUX>(a, b, om, t, y, h0_c, om_c);
+        modulate(h, a, b, om, time);
     }
 
     // Wave-vector terms of the lane's 16 texels (spectrum_modulate.glsl:60-62).  kx of slot j is

@@ -102,6 +102,32 @@ __device__ __forceinline__ void load_twiddles(cplx *tw_lds, const cplx *__restri
     lds_barrier();
 }
 
+// The same in two steps: tw_fetch issues the table loads FIRST in the kernel, tw_commit (after the kernel has issued its own
+// first data loads) puts them into LDS and runs the barrier.  The barrier then waits for the table only -- memory returns in
+// order, and the table was asked for first -- instead of standing behind every wave's data loads.
+template <int N>
+struct TwPrefetch {
+    static constexpr int K = (plan_tw_total(N) + plan_wg_threads(N) - 1) / plan_wg_threads(N);
+    cplx v[K];
+};
+template <int N>
+__device__ __forceinline__ void tw_fetch(TwPrefetch<N> &p, const cplx *__restrict__ tw) {
+#pragma unroll
+    for (int k = 0; k < TwPrefetch<N>::K; ++k) {
+        const int i = (int)threadIdx.x + k * plan_wg_threads(N);
+        p.v[k] = tw[i < plan_tw_total(N) ? i : 0];
+    }
+}
+template <int N>
+__device__ __forceinline__ void tw_commit(const TwPrefetch<N> &p, cplx *tw_lds) {
+#pragma unroll
+    for (int k = 0; k < TwPrefetch<N>::K; ++k) {
+        const int i = (int)threadIdx.x + k * plan_wg_threads(N);
+        if (i < plan_tw_total(N)) tw_lds[i] = p.v[k];
+    }
+    lds_barrier();
+}
+
 // row IFFT of the 16 points in d[] (lane t of the row), exchanging through this row's LDS buffer
 // (BLOCK_GATE: a workgroup barrier right before the first write into the row regions -- pass 1 uses it when
 // other waves may still be draining the previous layer's staged rows out of them)
@@ -413,9 +439,16 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
 
     cplx h[P];
-    Pass1<N>::template load_modulate<AUX_H>(h, t, y, h0_c, om_c, cf.time);
+    {
+        TwPrefetch<N> twp;
+        tw_fetch<N>(twp, buf.tw);
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
+        tw_commit<N>(twp, tw_lds);
+        Pass1<N>::modulate(h, a, b, om, cf.time);
+    }
     stamp(1, h[0].x);
-    load_twiddles<N>(tw_lds, buf.tw);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
@@ -528,9 +561,11 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     {
         cplx f2[P];
         OW_SCHED_FENCE();
+        TwPrefetch<N> twp;
+        tw_fetch<N>(twp, buf.tw);
         Pass2<N>::template load_c1<AUX_T>(f2, t, xp, dky, T_c);
         const cplx r2 = side_row(2);
-        load_twiddles<N>(tw_lds, buf.tw);
+        tw_commit<N>(twp, tw_lds);
         Pass2<N>::put_row0(f2, t, r2);
         row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
@@ -608,8 +643,15 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
     const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
     cplx h[P];
-    Pass1<N>::load_modulate(h, t, y, h0_c, om_c, cf.time);
-    load_twiddles<N>(tw_lds, buf.tw);
+    {
+        TwPrefetch<N> twp;
+        tw_fetch<N>(twp, buf.tw);
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::load_raw(a, b, om, t, y, h0_c, om_c);
+        tw_commit<N>(twp, tw_lds);
+        Pass1<N>::modulate(h, a, b, om, cf.time);
+    }
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
@@ -663,11 +705,13 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
     init_row_sync<N>(sync_flags, ROWS * kLayers);
 
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
     cplx d[P];
     Pass2<N>::template load_layer<AUX_T>(d, t, xp, g, T_c);
     // this group's quarter of the lane's foam values (o = 4g .. 4g+3): 8 bytes of the lane's 32
     const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
-    load_twiddles<N>(tw_lds, buf.tw);
+    tw_commit<N>(twp, tw_lds);
     row_ifft<N>(d, t, region(r, g), tw_lds, rs);
     rs.sync();
     {
@@ -725,8 +769,15 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
     const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
     const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
     cplx h[P];
-    Pass1<N>::load_modulate(h, t, y, h0_c, om_c, cf.time);
-    load_twiddles<N>(tw_lds, buf.tw);
+    {
+        TwPrefetch<N> twp;
+        tw_fetch<N>(twp, buf.tw);
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::load_raw(a, b, om, t, y, h0_c, om_c);
+        tw_commit<N>(twp, tw_lds);
+        Pass1<N>::modulate(h, a, b, om, cf.time);
+    }
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
@@ -787,6 +838,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
     init_row_sync<N>(sync_flags, ROWS * kLayers);
 
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
     cplx d[P];
     switch (g) {  // group-uniform
         case 0: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 0, T_c); break;
@@ -799,7 +852,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     }
     if (g != 0) Pass2<N>::put_row0(d, t, gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
     const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
-    load_twiddles<N>(tw_lds, buf.tw);
+    tw_commit<N>(twp, tw_lds);
     row_ifft<N>(d, t, region(r, g), tw_lds, rs);
     rs.sync();
     {

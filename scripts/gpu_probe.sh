@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "long_run" 2>&1 | tail -12
+timeout 800 python -m pytest tests -m gpu -q 2>&1 | tail -3
+timeout 300 python scripts/mode_bench.py 256:1 128:4 128:1 2>&1 | grep -E "None"
