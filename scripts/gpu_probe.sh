@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 200 ./tools/kbench 4 30 > gpurun_out/kbench.log 2>&1; grep -A12 "k_pass1c phases" gpurun_out/kbench.log
+timeout 300 python scripts/mode_bench.py 1024:4 1024:1 2048:1 512:4 2>&1 | grep -E "None"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3
