@@ -38,6 +38,9 @@ struct SurfaceSample {
     float foam;
     float normal_factor, foam_factor, scale_factor;
     int32_t spray_active;
+    float gradient_fragment[2];
+    float foam_fragment;
+    float reserved;
 };
 hipError_t launch_sample_surface(int n, int cascades, const DeviceBuffers &buf, const float *xz_dev, int count,
                                  const SurfaceScales &scales, SurfaceSample *out_dev, hipStream_t s);

@@ -470,7 +470,7 @@ ow_status ow_readback_wait(ow_context *c, int32_t cascade, const void **disp, co
 
 ow_status ow_sample_surface(ow_context *c, const float *xz, int32_t count, const float *map_scales, int32_t num_cascades,
                             ow_surface_sample *out) {
-    static_assert(sizeof(ow_surface_sample) == sizeof(ow::SurfaceSample) && sizeof(ow_surface_sample) == 48, "record layout");
+    static_assert(sizeof(ow_surface_sample) == sizeof(ow::SurfaceSample) && sizeof(ow_surface_sample) == 64, "record layout");
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (count < 0) return fail(OW_ERR_INVALID, "count must be >= 0");
     if (num_cascades < 1 || num_cascades > c->cascades) return fail(OW_ERR_INVALID, "num_cascades %d outside [1,%d]", num_cascades, c->cascades);

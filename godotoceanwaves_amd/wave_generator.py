@@ -235,7 +235,8 @@ class WaveGenerator:
     # ---- consumer-side sampling on the device (water.gdshader:27-39,72-82; sea_spray_particle.gdshader:78-96) ----
     SURFACE_SAMPLE = np.dtype([("displacement", np.float32, 3), ("gradient", np.float32, 2), ("gradient_scaled", np.float32, 2),
                                ("foam", np.float32), ("normal_factor", np.float32), ("foam_factor", np.float32),
-                               ("scale_factor", np.float32), ("spray_active", np.int32)])
+                               ("scale_factor", np.float32), ("spray_active", np.int32), ("gradient_fragment", np.float32, 2),
+                               ("foam_fragment", np.float32), ("reserved", np.float32)])
 
     def sample_surface(self, world_xz, map_scales):
         """Evaluate the water vertex/fragment sums and the sea-spray spawn mask at world points [P][2] (x, z);

@@ -175,6 +175,10 @@ typedef struct ow_surface_sample {
     float foam_factor;        /* :86: mix(0.25, 1, min((foam - 0.9) / 0.1, 1)) */
     float scale_factor;       /* :89 SCALE_FACTOR = normal_factor * foam_factor */
     int32_t spray_active;     /* :88 ACTIVE = normal_factor in [0,1] && foam > 0.9: the sea-spray spawn mask */
+    float gradient_fragment[2]; /* water.gdshader:74-82 fragment(): sum_i mix(texture_bicubic, texture, min(1, 0.1 * map_size *
+                                   min(scales_i.xy))).xy * scales_i.w -- the cubic B-spline filter of :41-68 included */
+    float foam_fragment;        /* the same mix, .w */
+    float reserved;
 } ow_surface_sample;
 
 /* Samples layers 0..num_cascades-1 at `count` points (world_xz = x0,z0,x1,z1,...; map_scales = 4 floats per cascade;

@@ -86,7 +86,8 @@ def lib(native=False):
 
 SURFACE_SAMPLE = np.dtype([("displacement", np.float32, 3), ("gradient", np.float32, 2), ("gradient_scaled", np.float32, 2),
                            ("foam", np.float32), ("normal_factor", np.float32), ("foam_factor", np.float32),
-                           ("scale_factor", np.float32), ("spray_active", np.int32)])
+                           ("scale_factor", np.float32), ("spray_active", np.int32), ("gradient_fragment", np.float32, 2),
+                           ("foam_fragment", np.float32), ("reserved", np.float32)])
 
 
 def sample_surface(displacements, normals, map_scales, world_xz):

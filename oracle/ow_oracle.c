@@ -516,6 +516,33 @@ static void texture_linear_repeat(const uint16_t *layer, int n, float u, float v
 
 static float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; } /* GLSL mix() */
 
+/* water.gdshader:41-51 cubic_weights, :53-68 texture_bicubic: cubic B-spline filtering as four bilinear taps */
+static void cubic_weights(float a, float w[4]) {
+    float a2 = a * a, a3 = a2 * a;
+    w[0] = (-a3 + a2 * 3.0f - a * 3.0f + 1.0f) / 6.0f;
+    w[1] = (a3 * 3.0f - a2 * 6.0f + 4.0f) / 6.0f;
+    w[2] = (-a3 * 3.0f + a2 * 3.0f + a * 3.0f + 1.0f) / 6.0f;
+    w[3] = a3 / 6.0f;
+}
+static void texture_bicubic(const uint16_t *layer, int n, float u, float v, float out[4]) {
+    const float dims = (float)n, dims_inv = 1.0f / dims;
+    const float x = u * dims + 0.5f, y = v * dims + 0.5f;
+    const float fx = x - floorf(x), fy = y - floorf(y);
+    float wx[4], wy[4];
+    cubic_weights(fx, wx);
+    cubic_weights(fy, wy);
+    const float gx0 = wx[0] + wx[1], gx1 = wx[2] + wx[3], gy0 = wy[0] + wy[1], gy1 = wy[2] + wy[3];
+    const float hx0 = (wx[1] / gx0 + -1.5f + floorf(x)) * dims_inv, hx1 = (wx[3] / gx1 + 0.5f + floorf(x)) * dims_inv;
+    const float hy0 = (wy[1] / gy0 + -1.5f + floorf(y)) * dims_inv, hy1 = (wy[3] / gy1 + 0.5f + floorf(y)) * dims_inv;
+    const float wgx = gx0 / (gx0 + gx1), wgy = gy0 / (gy0 + gy1);
+    float t_yw[4], t_xw[4], t_yz[4], t_xz[4]; /* texture(h.yw), (h.xw), (h.yz), (h.xz) */
+    texture_linear_repeat(layer, n, hx1, hy1, t_yw);
+    texture_linear_repeat(layer, n, hx0, hy1, t_xw);
+    texture_linear_repeat(layer, n, hx1, hy0, t_yz);
+    texture_linear_repeat(layer, n, hx0, hy0, t_xz);
+    for (int k = 0; k < 4; ++k) out[k] = mixf(mixf(t_yw[k], t_xw[k], wgx), mixf(t_yz[k], t_xz[k], wgx), wgy);
+}
+
 void owo_sample_surface(int n, int num_cascades, const uint16_t *displacements, const uint16_t *normals,
                         const float *map_scales, const float *world_xz, int count, owo_surface_sample *out) {
     const size_t layer = (size_t)n * n * 4;
@@ -536,6 +563,16 @@ void owo_sample_surface(int n, int num_cascades, const uint16_t *displacements, 
             s.gradient_scaled[0] += g[0] * scales[3];
             s.gradient_scaled[1] += g[1] * scales[3];
             s.foam += g[3];
+            /* water.gdshader:74-82 fragment(): bicubic and bilinear mixed by the pixels per metre of this cascade */
+            {
+                float bc[4];
+                const float ppm = (float)n * fminf(scales[0], scales[1]);
+                const float a = fminf(1.0f, ppm * 0.1f);
+                texture_bicubic(normals + layer * i, n, x * scales[0], z * scales[1], bc);
+                s.gradient_fragment[0] += mixf(bc[0], g[0], a) * scales[3];
+                s.gradient_fragment[1] += mixf(bc[1], g[1], a) * scales[3];
+                s.foam_fragment += mixf(bc[3], g[3], a) * 1.0f;
+            }
         }
         /* sea_spray_particle.gdshader:83-89 */
         float nx = -s.gradient[0], ny = 1.0f, nz = -s.gradient[1];

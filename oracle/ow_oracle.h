@@ -134,6 +134,9 @@ typedef struct {
     float foam;
     float normal_factor, foam_factor, scale_factor;
     int32_t spray_active;
+    float gradient_fragment[2]; /* water.gdshader:81, bicubic / bilinear mix included */
+    float foam_fragment;
+    float reserved;
 } owo_surface_sample;
 /* displacements / normals: [num_cascades][n][n][4] FP16 bits; map_scales: 4 floats per cascade (water.gd:105-109) */
 void owo_sample_surface(int n, int num_cascades, const uint16_t *displacements, const uint16_t *normals,

@@ -40,3 +40,33 @@ def d_dz_world(field, tile_length_y):
     n = field.shape[0]
     k = 2.0 * np.pi * np.fft.fftfreq(n, d=tile_length_y / n)
     return np.real(np.fft.ifft(np.fft.fft(field.astype(np.float64), axis=0) * (1j * k)[:, None], axis=0))
+
+
+def texture_bspline(img, u, v):
+    """Cubic B-spline filtering of img[row, col, channel] at normalised (u, v), written directly as the 4 x 4-tap weighted sum
+    (water.gdshader:53-68 gets the same value from four bilinear taps, GPU Gems 2 ch. 20); repeat addressing"""
+    n_rows, n_cols = img.shape[:2]
+    x, y = np.asarray(u, np.float64) * n_cols - 0.5, np.asarray(v, np.float64) * n_rows - 0.5
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+    fx, fy = x - x0, y - y0
+
+    def weights(a):
+        return [(-a ** 3 + 3 * a ** 2 - 3 * a + 1) / 6, (3 * a ** 3 - 6 * a ** 2 + 4) / 6, (-3 * a ** 3 + 3 * a ** 2 + 3 * a + 1) / 6, a ** 3 / 6]
+
+    wx, wy = weights(fx), weights(fy)
+    out = 0.0
+    for b in range(4):
+        for a in range(4):
+            out = out + (wx[a] * wy[b])[..., None] * img[(y0 - 1 + b) % n_rows, (x0 - 1 + a) % n_cols]
+    return out
+
+
+def gradient_fragment_at(norm_maps, map_scales, world_x, world_z):
+    """water.gdshader:74-82: sum over cascades of mix(bicubic, bilinear, min(1, 0.1 * map_size * min(scales.xy))).xyw * (scales.ww, 1)"""
+    out = 0.0
+    for img, (sx, sy, _, sw) in zip(norm_maps, map_scales):
+        img = np.asarray(img, np.float64)
+        a = min(1.0, 0.1 * img.shape[0] * min(sx, sy))
+        val = texture_bspline(img, world_x * sx, world_z * sy) * (1 - a) + texture_bilinear(img, world_x * sx, world_z * sy) * a
+        out = out + val[..., [0, 1, 3]] * np.array([sw, sw, 1.0])
+    return out

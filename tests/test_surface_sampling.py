@@ -33,7 +33,7 @@ def query_points(count, seed=1, span=700.0):
 
 def test_record_layout_is_the_same_on_every_side():
     from godotoceanwaves_amd import WaveGenerator
-    assert O.SURFACE_SAMPLE.itemsize == 48 and WaveGenerator.SURFACE_SAMPLE == O.SURFACE_SAMPLE
+    assert O.SURFACE_SAMPLE.itemsize == 64 and WaveGenerator.SURFACE_SAMPLE == O.SURFACE_SAMPLE
 
 
 def test_oracle_sampling_agrees_with_fp64_consumer_view():
@@ -50,6 +50,21 @@ def test_oracle_sampling_agrees_with_fp64_consumer_view():
     gs = sum(K.texture_bilinear(m[i].astype(np.float64), x * sc[i, 0], z * sc[i, 1])[..., :2] * sc[i, 3] for i in range(3))
     assert np.abs(o["gradient"] - g[..., :2])[near].max() < 1e-4 and np.abs(o["foam"] - g[..., 3])[near].max() < 1e-4
     assert np.abs(o["gradient_scaled"] - gs)[near].max() < 1e-4
+
+
+def test_oracle_fragment_filter_agrees_with_the_direct_b_spline_sum():
+    """water.gdshader:41-82: the four-bilinear-tap cubic B-spline and its mix with the bilinear lookup, against the direct
+    16-tap sum; one cascade coarse enough (and one fine enough) for the mix factor to be below / at 1"""
+    d, m = random_maps(3, 64)
+    sc = np.array([[1 / 880, 1 / 880, 1.0, 1.3], [1 / 5, 1 / 4, 0.75, 0.5], [1 / 16, 1 / 9, 0.5, 0.25]], np.float32)
+    assert min(1.0, 0.1 * 64 * sc[0, 0]) < 1 and min(1.0, 0.1 * 64 * min(sc[1, 0], sc[1, 1])) == 1.0
+    xz = query_points(2000, span=300.0)
+    o = O.sample_surface(d, m, sc, xz)
+    ref = K.gradient_fragment_at([m[i] for i in range(3)], sc.astype(np.float64), xz[:, 0].astype(np.float64), xz[:, 1].astype(np.float64))
+    near = np.abs(xz).max(axis=1) < 100.0
+    assert np.abs(o["gradient_fragment"] - ref[:, :2])[near].max() < 2e-4
+    assert np.abs(o["foam_fragment"] - ref[:, 2])[near].max() < 2e-4
+    assert np.abs(o["gradient_fragment"] - o["gradient_scaled"]).max() > 1e-2     # the filter is not a no-op
 
 
 def test_spray_mask_cases():
