@@ -184,7 +184,7 @@ def main():
     gen.timing(False)
     family = gen.last_kernel_family()
     suffix = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}[family]
-    per_launch = min(C, max(1, (4 << 20) // (n * n)))  # cascades per launch (the runtime batches so that T stays in the Infinity Cache)
+    per_launch = gen.last_batch_cascades()  # cascades per pair of launches (the runtime may split a tick: ow_runtime.hip batch_size)
     sync_all()
 
     if rank == 0:

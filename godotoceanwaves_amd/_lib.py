@@ -48,6 +48,7 @@ SIGNATURES = {
     "ow_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),
     "ow_cascades_remaining": (C.c_int32, [C.c_void_p]),
     "ow_last_kernel_family": (C.c_int32, [C.c_void_p]),
+    "ow_last_batch_cascades": (C.c_int32, [C.c_void_p]),
     "ow_sync": (C.c_int, [C.c_void_p]),
     "ow_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
     "ow_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

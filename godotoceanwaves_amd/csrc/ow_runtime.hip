@@ -83,9 +83,21 @@ namespace {
 
 size_t plane(const ow_context *c) { return (size_t)c->n * c->n; }
 
-// cascades per pair of launches: at most 4 Mi texels, so that the 32 B/texel intermediate (<= 128 MiB) is still in the
-// 256 MiB Infinity Cache when pass 2 reads it
-int batch_size(const ow_context *c) { return std::max(1, (int)((4u << 20) / ((size_t)c->n * c->n))); }
+// Cascades per pair of launches (measured at 1024^2, scripts/mode_bench.py): a tick of up to 6 Mi texels goes in ONE pair
+// (x 5: 82 us against 84.5 as 4 + 1; x 6: 88.5 against 96); beyond that the intermediate and the inputs of a pair no
+// longer fit the 256 MiB Infinity Cache together (x 8 in one pair: 126-137 us, erratic) and the tick is split into equal
+// batches of at most 4 Mi texels (x 7: 4 + 3, x 8: 4 + 4 = 121-125 us; 2048^2: one cascade per pair).
+constexpr size_t kSinglePairTexels = 6u << 20, kBatchTexels = 4u << 20;
+int max_batch(const ow_context *c) {  // the most cascades a pair ever takes: sizes the scratch buffers
+    const size_t pl = (size_t)c->n * c->n;
+    return std::max(1, (int)std::max(kSinglePairTexels / pl, kBatchTexels / pl));
+}
+int batch_size(const ow_context *c, int count) {
+    const size_t pl = (size_t)c->n * c->n;
+    if ((size_t)count * pl <= kSinglePairTexels) return count;
+    const int cap = std::max(1, (int)(kBatchTexels / pl)), batches = (count + cap - 1) / cap;
+    return (count + batches - 1) / batches;
+}
 
 constexpr size_t kMaxTimedBatches = 4096;
 
@@ -155,11 +167,8 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
         cf.cascade = idx[i];
     }
-    // Launch in batches whose transposed intermediate (32 B/texel) stays inside the 256 MiB Infinity Cache between
-    // pass 1 and pass 2: at most 4 Mi texels (= 1024^2 x 4 = 128 MiB of T) per pair of launches.  Larger batches
-    // would stream T through HBM twice; smaller ones only add launches.  Cascades are independent, so batching does
-    // not change any result.
-    const int per_batch = batch_size(c);
+    // Launch in batches of batch_size() cascades (see there).  Cascades are independent, so batching does not change any result.
+    const int per_batch = batch_size(c, count);
     for (int b0 = 0; b0 < count; b0 += per_batch) {
         const int nb = std::min(per_batch, count - b0);
         ow::FrameArgs part;
@@ -270,7 +279,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
-    OW_ALLOC(c->buf.T, (size_t)std::min((int)L, batch_size(c)) * pl * ow::kLayers * sizeof(ow::cplx));
+    OW_ALLOC(c->buf.T, (size_t)std::min((int)L, max_batch(c)) * pl * ow::kLayers * sizeof(ow::cplx));
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -286,7 +295,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
     if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
     {   // side buffers of the compact intermediate, one batch worth like T
-        const size_t slots = (size_t)std::min((int)L, batch_size(c));
+        const size_t slots = (size_t)std::min((int)L, max_batch(c));
         OW_ALLOC(c->buf.pcol, slots * c->n * sizeof(ow::cplx));
         OW_ALLOC(c->buf.rrow, slots * c->n * 4 * sizeof(ow::cplx));
     }
@@ -393,6 +402,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
 }
 
 int32_t ow_last_kernel_family(const ow_context *c) { return c ? c->last_family : 0; }
+int32_t ow_last_batch_cascades(const ow_context *c) { return c ? c->last_count : 0; }
 
 int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_cascades_remaining : 0; }
 

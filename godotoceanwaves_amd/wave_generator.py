@@ -269,6 +269,10 @@ class WaveGenerator:
         """which kernels the most recent batch ran with: "standard", "layer_parallel", "compact" (None before the first launch)"""
         return self.KERNEL_FAMILIES[int(self._lib.ow_last_kernel_family(self.context))]
 
+    def last_batch_cascades(self):
+        """cascades in the most recent pair of launches (a tick may be split into several pairs)"""
+        return int(self._lib.ow_last_batch_cascades(self.context))
+
     def timing(self, enable):
         _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
 

@@ -217,6 +217,8 @@ ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_a
  * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c), 4 = layer-parallel on the compact intermediate (k_pass1c_lp /
  * k_pass2c_lp); 0 before the first launch. */
 int32_t ow_last_kernel_family(const ow_context *ctx);
+/* Number of cascades the most recent pair of launches processed (the runtime may split a tick into several pairs). */
+int32_t ow_last_batch_cascades(const ow_context *ctx);
 
 /* Benchmark probe: average duration (ms) of each frame kernel alone, from `reps` back-to-back launches of pass 1
  * and then `reps` of pass 2 with the arguments of the most recent batch, bracketed by hipEvents on the context's

@@ -173,11 +173,11 @@ def test_full_size_properties(n):
 
 
 @pytest.mark.parametrize("kernels", [None, "standard"])
-@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (2048, [0, 2])])
-def test_batched_launches_match_oracle(n, ids, kernels):
-    """More cascades than one pair of launches takes (the runtime batches at 4 Mi texels and reuses the scratch
-    intermediate between batches): every cascade still matches the oracle, two frames.  kernels=None is the runtime's own
-    choice (the compact-intermediate kernels at these sizes)."""
+@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]), (2048, [0, 2]), (2048, [0, 1, 2])])
+def test_many_cascades_and_batched_launches_match_oracle(n, ids, kernels):
+    """Five cascades of 1024^2 in one pair of launches, and more cascades than one pair takes at 2048^2 (the runtime batches
+    there at 4 Mi texels = one cascade and reuses the scratch intermediate between batches): every cascade still matches the
+    oracle, two frames.  kernels=None is the runtime's own choice (the compact-intermediate kernels at these sizes)."""
     gen, params = make_gen(n, ids, kernels=kernels)
     og = H.oracle_generator(n, ids)
     for frame in range(2):
@@ -191,15 +191,20 @@ def test_batched_launches_match_oracle(n, ids, kernels):
                 assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
             else:
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
-    family = gen.last_kernel_family()        # of the LAST batch (1024^2: cascade 0 alone -> layer-parallel compact; 2048^2: one cascade -> compact)
-    assert family == "standard" if kernels == "standard" else "compact" in family
-    with pytest.raises(_lib.OceanWavesError):
-        gen.get_intermediate(len(ids) - 1)   # first batch's scratch has been overwritten by the last batch (update_all drains highest index first)
-    if "compact" in family:
+    family = gen.last_kernel_family()        # of the LAST batch
+    assert family == ("standard" if kernels == "standard" else "compact")
+    split = n == 2048 or len(ids) > 6        # 1024^2: one pair up to 6 cascades, 7 go as 4 + 3
+    assert gen.last_batch_cascades() == (1 if n == 2048 else (3 if len(ids) == 7 else len(ids)))
+    if split:       # drained highest index first: only the last batch's (lowest indices') intermediate is still there
+        with pytest.raises(_lib.OceanWavesError):
+            gen.get_intermediate(len(ids) - 1)
+    if family == "compact":
         with pytest.raises(_lib.OceanWavesError):
             gen.get_intermediate(0)          # the compact intermediate has no counterpart in the reference's fft_buffer
     else:
         assert gen.get_intermediate(0).shape == (4, n, n, 2)
+        if not split:
+            assert gen.get_intermediate(len(ids) - 1).shape == (4, n, n, 2)   # one batch: every cascade's intermediate is there
 
 
 def _edge_cases():
