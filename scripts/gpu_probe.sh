@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 800 python -m pytest tests -m gpu -q 2>&1 | tail -4
-timeout 300 python scripts/mode_bench.py 1024:8 1024:7 1024:6 1024:5 1024:4 2>&1 | grep -E "None"
-timeout 200 python bench.py --no-cpu-baseline --cascades 8 2>&1 | tail -1 | cut -c1-200
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu 2>&1 | grep -E '^\{' | cut -c1-400
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 300 --warmup 20 --backend gloo --share-gpu --cascades 1 --gather-every 50 2>&1 | grep -E '^\{' | cut -c1-400
