@@ -15,6 +15,14 @@ constant of the shader is kept verbatim:
   * `case N:` ... `break;`                        -> `case N: {` ... `break; }` (C++ forbids jumping over the
                                                      initialised declarations GLSL allows inside a switch)
 `in` parameter qualifiers, `shared`, `restrict`, ... are handled by macros in glsl_shim.h.
+
+glsl_prep.py --extract SRC.gdshader DST.inc [--define NAME]... [--function NAME]... [--block NAME START END EPILOGUE]...
+Godot spatial / particle shaders (.gdshader) are not GLSL translation units (shader_type, render_mode, hinted uniforms,
+built-ins such as VERTEX / UV / ACTIVE), so they are not converted whole: the named `#define`s, the named function
+definitions (verbatim, brace-matched) and the named statement ranges of vertex() / fragment() / process() are copied out.
+A --block is the lines from the first one matching regex START to the first later one matching regex END (inclusive),
+wrapped as `static void NAME() { ...lines...; EPILOGUE }` -- the epilogue (C++ written by the caller) only copies the
+block's local results into globals of the including namespace; the statements themselves are the reference's text.
 """
 import re
 import sys
@@ -82,7 +90,78 @@ def convert(text):
     return "\n".join(out) + "\n"
 
 
+def literals(code):
+    return FLOAT_LIT.sub(lambda m: m.group(1) + "f", code)
+
+
+def extract(text, defines, functions, blocks):
+    text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)
+    lines = text.split("\n")
+    out = []
+    for name in defines:
+        hit = [ln for ln in lines if re.match(r"\s*#define\s+%s\b" % re.escape(name), ln)]
+        if len(hit) != 1:
+            raise SystemExit("#define %s: %d matches" % (name, len(hit)))
+        out.append(literals(split_comment(hit[0])[0]))
+    for name in functions:
+        start = [i for i, ln in enumerate(lines) if re.match(r"\w+\s+%s\s*\(" % re.escape(name), ln)]
+        if len(start) != 1:
+            raise SystemExit("function %s: %d definitions" % (name, len(start)))
+        depth, i, seen = 0, start[0], False
+        while True:
+            code = split_comment(lines[i])[0]
+            out.append(literals(code))
+            depth += code.count("{") - code.count("}")
+            seen = seen or "{" in code
+            if seen and depth == 0:
+                break
+            i += 1
+    for name, start_re, end_re, epilogue in blocks:
+        first = [i for i, ln in enumerate(lines) if re.search(start_re, ln)]
+        if not first:
+            raise SystemExit("block %s: start %r not found" % (name, start_re))
+        # several places may open with the same statement (e.g. `vec3 displacement = vec3(0);`): the caller picks by ordinal
+        m = re.match(r"(.*)#(\d+)$", name)
+        ordinal = int(m.group(2)) if m else 0
+        name = m.group(1) if m else name
+        i = first[ordinal]
+        out.append("static void %s() {" % name)
+        while True:
+            code = split_comment(lines[i])[0]
+            out.append(literals(code))
+            if i > first[ordinal] and re.search(end_re, lines[i]) or (i == first[ordinal] and start_re == end_re):
+                break
+            i += 1
+            if i >= len(lines):
+                raise SystemExit("block %s: end %r not found" % (name, end_re))
+        out.append(epilogue)
+        out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def main_extract(argv):
+    src, dst, rest = argv[0], argv[1], argv[2:]
+    defines, functions, blocks = [], [], []
+    while rest:
+        if rest[0] == "--define":
+            defines.append(rest[1]); rest = rest[2:]
+        elif rest[0] == "--function":
+            functions.append(rest[1]); rest = rest[2:]
+        elif rest[0] == "--block":
+            blocks.append(tuple(rest[1:5])); rest = rest[5:]
+        else:
+            raise SystemExit("unknown argument " + rest[0])
+    with open(src) as f:
+        text = f.read()
+    with open(dst, "w") as f:
+        f.write("// GENERATED by oracle/glsl_prep.py --extract from %s -- do not commit\n" % src)
+        f.write(extract(text, defines, functions, blocks))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--extract":
+        main_extract(sys.argv[2:])
+        sys.exit(0)
     src, dst = sys.argv[1], sys.argv[2]
     with open(src) as f:
         text = f.read()

@@ -98,6 +98,8 @@ static void dispatch(void (*shader_main)(), const uvec3 &size, uint gx, uint gy,
 
 #define GLSL_USING                                                                                            \
     using glsl::vec2; using glsl::vec4; using glsl::ivec2; using glsl::ivec3; using glsl::uvec2; using glsl::uvec3; \
+    using glsl::vec3; using glsl::sampler2DArray; using glsl::texture; using glsl::textureSize; using glsl::fract;  \
+    using glsl::floor; using glsl::normalize;                                                                  \
     using glsl::image2DArray; using glsl::cos; using glsl::sin; using glsl::exp; using glsl::log; using glsl::sqrt; \
     using glsl::inversesqrt; using glsl::pow; using glsl::atan; using glsl::abs; using glsl::min; using glsl::max; \
     using glsl::clamp; using glsl::mix; using glsl::length; using glsl::mod; using glsl::floatBitsToUint;      \
@@ -162,6 +164,38 @@ GLSL_USING
 #undef FFT_DATA
 }  // namespace sh_fft_unpack
 
+// ---- the map-reading parts of the spatial / particle shaders --------------------------------
+// .gdshader files are not GLSL translation units; oracle/Makefile has glsl_prep.py --extract copy out, verbatim, the
+// functions cubic_weights / texture_bicubic (water.gdshader:41-68), the cascade loops of vertex() (:31-37) and fragment()
+// (:72-82), and of the particle shader's process() the spawn decision (sea_spray_particle.gdshader:80-89) and the
+// displacement lookup (:103-107).  The uniforms and built-ins those statements name are the globals declared here.
+namespace sh_water {
+GLSL_USING
+#include "water_gdshader.inc.defs"
+vec4 map_scales[MAX_CASCADES];   // water.gdshader:18
+uint num_cascades;               // :19
+sampler2DArray displacements;    // :20
+sampler2DArray normals;          // :21
+vec2 UV;                         // built-in; vertex() sets UV = VERTEX.xz (:28) and fragment() receives it interpolated
+vec3 VERTEX;                     // built-in (only its distance to the camera is taken from it in the extracted range)
+vec3 out_displacement, out_gradient;
+#include "water_gdshader.inc"
+}  // namespace sh_water
+
+namespace sh_spray {
+GLSL_USING
+vec4 map_scales[8];              // sea_spray_particle.gdshader (group_uniforms cascade_data), MAX_CASCADES entries
+uint num_cascades;
+sampler2DArray displacements, normals;
+vec3 START_POS;                  // varying of the particle (its spawn position)
+bool ACTIVE;                     // built-in
+float SCALE_FACTOR;              // #define SCALE_FACTOR USERDATA1.w in the shader: a per-particle float
+vec3 out_displacement, out_gradient;
+float out_normal_factor, out_foam_factor;
+#include "sea_spray_particle_gdshader.inc"
+}  // namespace sh_spray
+
+#undef MAX_CASCADES
 #undef in
 #undef shared
 
@@ -263,6 +297,59 @@ void ref_fft_unpack(int n, float *fft, float whitecap, float foam_grow_rate, flo
     S::foam_grow_rate = foam_grow_rate;
     S::foam_decay_rate = foam_decay_rate;
     glsl::dispatch(S::shader_main, S::gl_WorkGroupSize, n / 16, n / 16, 1, true);
+}
+
+// Same record as owo_surface_sample (oracle/ow_oracle.h) / ow_surface_sample (include/ocean_waves.h).
+struct ref_surface_sample {
+    float displacement[3], gradient[2], gradient_scaled[2], foam, normal_factor, foam_factor, scale_factor;
+    int32_t spray_active;
+    float gradient_fragment[2], foam_fragment, reserved;
+};
+
+// What the reference's consumers read at world points (x, z): vertex() displacement sum, fragment() gradient / foam sum
+// (bicubic / bilinear mix), the particle shader's spawn decision and its own displacement sum (must equal vertex()'s).
+// gradient_scaled has no statement of its own in the reference (it is the bilinear operand of the mix in
+// water.gdshader:81) and stays zero here; `displacement_particle` receives sea_spray_particle.gdshader:103-107.
+void ref_sample_surface(int n, int num_cascades, const uint16_t *displacements, const uint16_t *normals, const float *map_scales,
+                        const float *world_xz, int count, ref_surface_sample *out, float *displacement_particle) {
+    namespace W = sh_water;
+    namespace P = sh_spray;
+    glsl::sampler2DArray d, m;
+    d.w = d.h = m.w = m.h = n;
+    d.layers = m.layers = num_cascades;
+    d.q = displacements;
+    m.q = normals;
+    W::displacements = P::displacements = d;
+    W::normals = P::normals = m;
+    W::num_cascades = P::num_cascades = (uint)num_cascades;
+    for (int i = 0; i < num_cascades; ++i)
+        W::map_scales[i] = P::map_scales[i] = glsl::vec4(map_scales[4 * i], map_scales[4 * i + 1], map_scales[4 * i + 2], map_scales[4 * i + 3]);
+    for (int p = 0; p < count; ++p) {
+        const float x = world_xz[2 * p], z = world_xz[2 * p + 1];
+        ref_surface_sample s;
+        memset(&s, 0, sizeof(s));
+        W::VERTEX = glsl::vec3(x, 0.0f, z);
+        W::UV = W::VERTEX.xz;  // water.gdshader:28
+        W::vertex_sum();
+        W::fragment_sum();
+        P::START_POS = glsl::vec3(x, 0.0f, z);
+        P::spawn();
+        P::follow();
+        for (int k = 0; k < 3; ++k) s.displacement[k] = W::out_displacement.d[k];
+        s.gradient_fragment[0] = W::out_gradient.x;
+        s.gradient_fragment[1] = W::out_gradient.y;
+        s.foam_fragment = W::out_gradient.z;
+        s.gradient[0] = P::out_gradient.x;
+        s.gradient[1] = P::out_gradient.y;
+        s.foam = P::out_gradient.z;
+        s.normal_factor = P::out_normal_factor;
+        s.foam_factor = P::out_foam_factor;
+        s.scale_factor = P::SCALE_FACTOR;
+        s.spray_active = P::ACTIVE ? 1 : 0;
+        out[p] = s;
+        if (displacement_particle)
+            for (int k = 0; k < 3; ++k) displacement_particle[3 * p + k] = P::out_displacement.d[k];
+    }
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // glsl_shim.h -- TEST INFRASTRUCTURE.  The subset of GLSL 4.60 that the six compute shaders of
-// 2Retr0/GodotOceanWaves (assets/shaders/compute/*.glsl) use, as C++: vector types with the swizzles that
+// 2Retr0/GodotOceanWaves (assets/shaders/compute/*.glsl) and the map-reading parts of its spatial / particle shaders
+// (assets/shaders/spatial/water.gdshader:27-84, sea_spray_particle.gdshader:78-107) use, as C++: vector types with the swizzles that
 // occur, the built-in functions that occur, image2DArray, shared memory and barrier().  With it the
 // reference's OWN shader sources (read where they lie under /root/reference, token-rewritten by glsl_prep.py
 // into oracle/_ref/, never committed) compile with g++ and execute on the CPU: that build is what pins the
@@ -27,17 +28,19 @@ namespace glsl {
 
 // ---- swizzle proxies ------------------------------------------------------------------------------
 // (LEN = number of components of the enclosing vector: a proxy must not enlarge it -- vec2 is 8 bytes in buffers)
-template <class V, class S, int A, int B, int LEN>
-struct Swz2 {
+template <class V, class S, int LEN, int... I>
+struct Swz {
     S v[LEN];
-    operator V() const { return V(v[A], v[B]); }
-    Swz2 &operator=(const V &o) {
-        S a = o.x, b = o.y;
-        v[A] = a;
-        v[B] = b;
+    operator V() const { return V(v[I]...); }
+    Swz &operator=(const V &o) {
+        const int idx[] = {I...};
+        const V c(o);
+        for (int k = 0; k < (int)sizeof...(I); ++k) v[idx[k]] = c.d[k];
         return *this;
     }
 };
+template <class V, class S, int A, int B, int LEN>
+using Swz2 = Swz<V, S, LEN, A, B>;
 
 #define GLSL_VEC_COMMON(V, S, NN)                                  \
     V(const V &o) { for (int i = 0; i < NN; ++i) d[i] = o.d[i]; } \
@@ -49,6 +52,8 @@ struct Swz2 {
     const S &operator[](int i) const { return d[i]; }
 
 struct vec2;
+struct vec3;
+struct vec4;
 struct ivec2;
 struct uvec2;
 
@@ -58,6 +63,8 @@ struct vec2 {
         float d[2];
         Swz2<vec2, float, 0, 1, 2> xy;
         Swz2<vec2, float, 1, 0, 2> yx;
+        Swz<vec4, float, 2, 0, 0, 1, 1> xxyy;
+        Swz<vec4, float, 2, 0, 1, 0, 1> xyxy;
     };
     vec2() : x(0), y(0) {}
     vec2(float a, float b) : x(a), y(b) {}
@@ -118,6 +125,21 @@ struct ivec3 {
     ivec3(const uvec2 &a, uint c) : x((int)a.x), y((int)a.y), z((int)c) {}
     GLSL_VEC_COMMON(ivec3, int, 3)
 };
+struct vec3 {
+    union {
+        struct { float x, y, z; };
+        float d[3];
+        Swz2<vec2, float, 0, 1, 3> xy;
+        Swz2<vec2, float, 0, 2, 3> xz;
+        Swz<vec3, float, 3, 0, 1, 2> xyz;
+    };
+    vec3() : x(0), y(0), z(0) {}
+    vec3(float a_, float b_, float c_) : x(a_), y(b_), z(c_) {}
+    explicit vec3(float a_) : x(a_), y(a_), z(a_) {}
+    vec3(const vec2 &a_, float c_) : x(a_.x), y(a_.y), z(c_) {}
+    vec3 &operator+=(const vec3 &o) { x = x + o.x; y = y + o.y; z = z + o.z; return *this; }
+    GLSL_VEC_COMMON(vec3, float, 3)
+};
 struct vec4 {
     union {
         struct { float x, y, z, w; };
@@ -125,6 +147,13 @@ struct vec4 {
         float d[4];
         Swz2<vec2, float, 0, 1, 4> xy;
         Swz2<vec2, float, 2, 3, 4> zw;
+        Swz2<vec2, float, 0, 2, 4> xz;
+        Swz2<vec2, float, 1, 3, 4> yw;
+        Swz2<vec2, float, 0, 3, 4> xw;
+        Swz2<vec2, float, 1, 2, 4> yz;
+        Swz2<vec2, float, 3, 3, 4> ww;
+        Swz<vec3, float, 4, 0, 1, 2> xyz;
+        Swz<vec3, float, 4, 0, 1, 3> xyw;
     };
     vec4() : x(0), y(0), z(0), w(0) {}
     vec4(float a_, float b_, float c_, float d_) : x(a_), y(b_), z(c_), w(d_) {}
@@ -154,6 +183,15 @@ inline uvec2 operator&(const uvec2 &a, const uvec2 &b) { return uvec2(a.x & b.x,
 inline uvec2 operator*(const uvec2 &a, uint s) { return uvec2(a.x * s, a.y * s); }
 inline uvec2 operator+(const uvec2 &a, const uvec2 &b) { return uvec2(a.x + b.x, a.y + b.y); }
 inline vec4 operator*(const vec4 &a, float s) { return vec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+// shapes used by the spatial / particle shaders (water.gdshader, sea_spray_particle.gdshader)
+inline vec2 operator+(const vec2 &a, float s) { return vec2(a.x + s, a.y + s); }
+inline vec3 operator*(const vec3 &a, const vec3 &b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator*(const vec3 &a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator/(const vec3 &a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+inline vec4 operator/(const vec4 &a, float s) { return vec4(a.x / s, a.y / s, a.z / s, a.w / s); }
+inline vec4 operator/(const vec4 &a, const vec4 &b) { return vec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+inline vec4 operator+(const vec4 &a, const vec4 &b) { return vec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+inline vec4 operator*(const vec4 &a, const vec4 &b) { return vec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
 // ---- built-in functions ------------------------------------------------------------------------------
 inline float cos(float x) { return ::cosf(x); }
@@ -175,6 +213,14 @@ inline float max(float a, float b) { return a < b ? b : a;  }  // GLSL: x < y ? 
 inline float clamp(float x, float lo, float hi) { return min(max(x, lo), hi); }
 inline float mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 inline float length(const vec2 &v) { return ::sqrtf(v.x * v.x + v.y * v.y); }
+inline float length(const vec3 &v) { return ::sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+inline vec3 normalize(const vec3 &v) { return v / length(v); }  // GLSL: x / length(x)
+inline float floor(float x) { return ::floorf(x); }
+inline vec2 floor(const vec2 &v) { return vec2(::floorf(v.x), ::floorf(v.y)); }
+inline vec2 fract(const vec2 &v) { return vec2(v.x - ::floorf(v.x), v.y - ::floorf(v.y)); }  // GLSL: x - floor(x)
+inline vec4 mix(const vec4 &x, const vec4 &y, float a) {
+    return vec4(mix(x.x, y.x, a), mix(x.y, y.y, a), mix(x.z, y.z, a), mix(x.w, y.w, a));
+}
 inline float mod(float x, float y) { return x - y * ::floorf(x / y); }
 inline vec2 mod(const ivec2 &x, const ivec2 &y) { return vec2(mod((float)x.x, (float)y.x), mod((float)x.y, (float)y.y)); }
 inline uint floatBitsToUint(float f) { uint u; memcpy(&u, &f, 4); return u; }
@@ -236,6 +282,36 @@ inline void imageStore(image2DArray &im, const ivec3 &p, const vec4 &v) {
     } else {
         for (int i = 0; i < 4; ++i) im.q[t + i] = f32_to_f16(v.d[i]);
     }
+}
+
+// ---- sampler2DArray over RGBA16F layers -------------------------------------------------------------------
+// texture(): GL_LINEAR minification/magnification, GL_REPEAT wrap, no mipmaps (the maps have one level), as the OpenGL 4.6
+// core specification 8.14.2 / Vulkan 16.8 define it: unnormalised coordinate u * size - 0.5, i0 = floor, weights alpha /
+// beta = the fractional parts, texel indices wrapped, tau = (1-a)(1-b) t00 + ... evaluated as two lerps along x then one
+// along y with exact FP32 weights (hardware quantises the weights to ~8 bits; the reference does not pin that).
+struct sampler2DArray {
+    int w = 0, h = 0, layers = 0;
+    const uint16_t *q = nullptr;  // [layers][h][w][4] FP16 bits
+};
+inline ivec3 textureSize(const sampler2DArray &s, int) { return ivec3(s.w, s.h, s.layers); }
+inline vec4 texture(const sampler2DArray &s, const vec3 &p) {
+    int layer = (int)::rintf(p.z);
+    layer = layer < 0 ? 0 : (layer >= s.layers ? s.layers - 1 : layer);
+    const uint16_t *t = s.q + (size_t)layer * s.w * s.h * 4;
+    const float un = p.x * (float)s.w - 0.5f, vn = p.y * (float)s.h - 0.5f;
+    const float fi = ::floorf(un), fj = ::floorf(vn);
+    const float a = un - fi, b = vn - fj;
+    long i0 = (long)fi % s.w, j0 = (long)fj % s.h;
+    if (i0 < 0) i0 += s.w;
+    if (j0 < 0) j0 += s.h;
+    const long i1 = (i0 + 1) % s.w, j1 = (j0 + 1) % s.h;
+    vec4 r;
+    for (int k = 0; k < 4; ++k) {
+        const float t00 = f16_to_f32(t[((size_t)j0 * s.w + i0) * 4 + k]), t10 = f16_to_f32(t[((size_t)j0 * s.w + i1) * 4 + k]);
+        const float t01 = f16_to_f32(t[((size_t)j1 * s.w + i0) * 4 + k]), t11 = f16_to_f32(t[((size_t)j1 * s.w + i1) * 4 + k]);
+        r.d[k] = (t00 * (1.0f - a) + t10 * a) * (1.0f - b) + (t01 * (1.0f - a) + t11 * a) * b;
+    }
+    return r;
 }
 
 // ---- invocation state + barrier (defined in glsl_ref.cpp) -----------------------------------------------------

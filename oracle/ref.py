@@ -37,6 +37,7 @@ def lib():
         L.ref_fft_compute.argtypes = [C.c_int, f32p, f32p]
         L.ref_transpose.argtypes = [C.c_int, f32p, f32p]
         L.ref_fft_unpack.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, u16p, u16p]
+        L.ref_sample_surface.argtypes = [C.c_int, C.c_int, u16p, u16p, f32p, f32p, C.c_int, C.c_void_p, f32p]
         _lib = L
     return _lib
 
@@ -96,3 +97,19 @@ class RefCascade:
         self.intermediate = self.fft[0].copy()                     # half 0 after the transpose
         L.ref_fft_compute(n, self.butterfly, flat)
         L.ref_fft_unpack(n, flat, p["whitecap"], grow, decay, self.displacement, self.normal)
+
+
+def sample_surface(displacements, normals, map_scales, world_xz):
+    """The reference's own consumer statements (water.gdshader:27-37,41-82, sea_spray_particle.gdshader:80-89,103-107, copied out
+    of the .gdshader files at build time by glsl_prep.py --extract) evaluated at world points.  Returns (records, displacement as
+    the particle shader sums it); records use oracle.SURFACE_SAMPLE's layout, `gradient_scaled` stays 0 (no statement of its
+    own in the reference)."""
+    from . import oracle as O
+    d = np.ascontiguousarray(np.asarray(displacements).view(np.uint16))
+    m = np.ascontiguousarray(np.asarray(normals).view(np.uint16))
+    sc = np.ascontiguousarray(map_scales, np.float32)
+    xz = np.ascontiguousarray(world_xz, np.float32)
+    out = np.zeros(len(xz), O.SURFACE_SAMPLE)
+    dp = np.zeros((len(xz), 3), np.float32)
+    lib().ref_sample_surface(d.shape[1], len(sc), d, m, sc, xz, len(xz), out.ctypes.data, dp)
+    return out, dp

@@ -19,17 +19,26 @@ CASES = [  # (map_size, cascade preset id, frames, row stride of the stored maps
     (128, 0, 3, 1),
     (128, 2, 3, 1),
     (256, 1, 2, 4),
+    # the reference's default size (water.gd:38) and the one below it: 1024-invocation workgroups of fft_compute.glsl
+    # run as fibers, ~40 s per frame at 1024^2 -- generated once, the files are committed
+    (512, 3, 2, 16),
+    (1024, 2, 2, 64),
+    (1024, 0, 1, 64),
 ]
 
 
 def main():
     if not R.available():
         raise SystemExit("oracle/_ref/libglsl_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    force = "--force" in sys.argv
     for n, ci, frames, stride in CASES:
+        out = os.path.join(HERE, f"ref_n{n}_c{ci}_f{frames}.npz")
+        if os.path.exists(out) and not force:   # committed fixtures are only rewritten on request
+            print(out, "exists (use --force to regenerate)")
+            continue
         rc = R.RefCascade(n, cascade_preset(ci))
         for _ in range(frames):
             rc.update(UPDATE_DELTA)
-        out = os.path.join(HERE, f"ref_n{n}_c{ci}_f{frames}.npz")
         np.savez_compressed(
             out, map_size=n, cascade=ci, frames=frames, row_stride=stride, delta=UPDATE_DELTA,
             spectrum_rows=rc.spectrum[::max(stride, 8)].copy(),          # FP32 h0 texels (subset of rows)

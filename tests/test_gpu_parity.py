@@ -173,9 +173,10 @@ def test_full_size_properties(n):
 
 
 @pytest.mark.parametrize("kernels", [None, "standard"])
-@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]), (2048, [0, 2]), (2048, [0, 1, 2])])
+@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]), (1024, [0, 1, 2, 3, 4, 5, 6, 7]), (2048, [0, 2]), (2048, [0, 1, 2])])
 def test_many_cascades_and_batched_launches_match_oracle(n, ids, kernels):
-    """Five cascades of 1024^2 in one pair of launches, and more cascades than one pair takes at 2048^2 (the runtime batches
+    """Five cascades of 1024^2 in one pair of launches, seven and MAX_CASCADES = 8 (water.gdshader:8; BASELINE config C4's per-node
+    total) as 4 + 3 and 4 + 4, and more cascades than one pair takes at 2048^2 (the runtime batches
     there at 4 Mi texels = one cascade and reuses the scratch intermediate between batches): every cascade still matches the
     oracle, two frames.  kernels=None is the runtime's own choice (the compact-intermediate kernels at these sizes)."""
     gen, params = make_gen(n, ids, kernels=kernels)
@@ -194,7 +195,7 @@ def test_many_cascades_and_batched_launches_match_oracle(n, ids, kernels):
     family = gen.last_kernel_family()        # of the LAST batch
     assert family == ("standard" if kernels == "standard" else "compact")
     split = n == 2048 or len(ids) > 6        # 1024^2: one pair up to 6 cascades, 7 go as 4 + 3
-    assert gen.last_batch_cascades() == (1 if n == 2048 else (3 if len(ids) == 7 else len(ids)))
+    assert gen.last_batch_cascades() == (1 if n == 2048 else {7: 3, 8: 4}.get(len(ids), len(ids)))
     if split:       # drained highest index first: only the last batch's (lowest indices') intermediate is still there
         with pytest.raises(_lib.OceanWavesError):
             gen.get_intermediate(len(ids) - 1)

@@ -22,7 +22,9 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)
 
 
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref/libglsl_ref.so not built (needs the reference checkout)")
-@pytest.mark.parametrize("n,ci,frames", [(128, 0, 3), (128, 3, 2), (256, 2, 1)])
+# 512^2 and 1024^2 (the reference's default size, water.gd:38; 10 stages of fft_compute.glsl:47-58): the 1024-invocation
+# workgroups run as fibers, ~15 s and ~40 s per frame -- one frame each
+@pytest.mark.parametrize("n,ci,frames", [(128, 0, 3), (128, 3, 2), (256, 2, 1), (512, 1, 1), (1024, 2, 1)])
 def test_oracle_is_bit_exact_against_the_reference_shaders(n, ci, frames):
     rc = R.RefCascade(n, cascade_preset(ci))
     g = H.oracle_generator(n, [ci])
@@ -61,7 +63,7 @@ def test_oracle_is_bit_exact_at_the_edges_of_the_parameter_ranges(name, preset):
 
 
 def test_golden_fixtures_exist():
-    assert len(GOLDEN) >= 3, "tests/golden/*.npz missing: run tests/golden/make_golden.py where /root/reference exists"
+    assert len(GOLDEN) >= 6 and any("n1024" in g for g in GOLDEN), "tests/golden/*.npz missing: run tests/golden/make_golden.py where /root/reference exists"
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])

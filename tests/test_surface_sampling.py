@@ -11,6 +11,7 @@ import helpers as H
 from godotoceanwaves_amd import _lib
 from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
 from oracle import oracle as O
+from oracle import ref as R
 
 SCALES3 = np.array([[1 / 88, 1 / 88, 1.0, 1.0], [1 / 57, 1 / 57, 0.75, 0.5], [1 / 16, 1 / 16, 0.5, 0.25]], np.float32)
 
@@ -34,6 +35,46 @@ def query_points(count, seed=1, span=700.0):
 def test_record_layout_is_the_same_on_every_side():
     from godotoceanwaves_amd import WaveGenerator
     assert O.SURFACE_SAMPLE.itemsize == 64 and WaveGenerator.SURFACE_SAMPLE == O.SURFACE_SAMPLE
+
+
+FIELDS_PINNED = ["displacement", "gradient", "foam", "normal_factor", "foam_factor", "scale_factor", "spray_active",
+                 "gradient_fragment", "foam_fragment"]
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref/libglsl_ref.so not built (needs the reference checkout)")
+@pytest.mark.parametrize("case", ["random_maps", "generated_maps", "spray_active", "fine_cascades"])
+def test_oracle_sampling_is_bit_exact_against_the_reference_shader_text(case):
+    """owo_sample_surface against the reference's OWN statements: cubic_weights / texture_bicubic (water.gdshader:41-68), the
+    cascade loops of vertex() (:31-37) and fragment() (:72-82), the particle shader's spawn decision
+    (sea_spray_particle.gdshader:80-89) and displacement sum (:103-107), compiled from the .gdshader files through
+    oracle/glsl_shim.h (texture() = GL_LINEAR + GL_REPEAT with exact weights, defined there)."""
+    sc = SCALES3
+    if case == "random_maps":
+        d, m = random_maps(3, 64)
+    elif case == "spray_active":  # foam near 1 and flat normals: ACTIVE both ways, both factor branches
+        d, m = random_maps(3, 32, seed=5, foam_hi=0.7)
+        m[..., :2] *= np.float16(0.1)
+    elif case == "fine_cascades":  # ppm * 0.1 >= 1 on every cascade: the mix takes the bilinear lookup alone
+        d, m = random_maps(3, 64, seed=7)
+        sc = np.array([[1 / 5, 1 / 4, 1.0, 1.3], [1 / 3, 1 / 6, 0.75, 0.5], [1 / 2, 1 / 2, 0.5, 0.25]], np.float32)
+    else:  # maps the pipeline itself produced (oracle generator), three cascades
+        g = H.oracle_generator(128, [0, 1, 2])
+        for _ in range(2):
+            g.update_all(UPDATE_DELTA)
+        d = np.stack([g.displacement(i) for i in range(3)])
+        m = np.stack([g.normal(i) for i in range(3)])
+    xz = query_points(3000, seed=11)
+    o = O.sample_surface(d, m, sc, xz)
+    r, dp = R.sample_surface(d, m, sc, xz)
+    for f in FIELDS_PINNED:
+        assert np.array_equal(o[f].view(np.uint32), r[f].view(np.uint32)), f
+    # the particle shader's own displacement sum (:103-107) is the vertex shader's (:31-37)
+    assert np.array_equal(dp.view(np.uint32), o["displacement"].view(np.uint32))
+    if case == "spray_active":
+        assert 0 < o["spray_active"].sum() < len(xz)
+    if case == "fine_cascades":  # gradient_scaled = the bilinear operand of water.gdshader:81's mix: pinned where the mix factor is 1
+        assert np.array_equal(o["gradient_scaled"].view(np.uint32), r["gradient_fragment"].view(np.uint32))
+        assert np.array_equal(o["foam"].view(np.uint32), r["foam_fragment"].view(np.uint32))
 
 
 def test_oracle_sampling_agrees_with_fp64_consumer_view():
