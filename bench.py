@@ -6,9 +6,15 @@
   step   : one simulation tick = time-modulate + 2-D IFFT + unpack/foam of all 4 cascades of this rank
            (steady state: the spectra h0 / omega are already resident in HBM; spectrum generation runs once
            during warm-up, like the reference's should_generate_spectrum path, and is reported separately)
-  N > 1  : cascades/tiles are independent units: every rank owns its own 4 cascades
-           (weak scaling, no data-path collective); one RCCL all_gather of the finished maps runs AFTER the
-           timed region ("final gather"), or every k ticks inside it with --gather-every k.
+  timing : W untimed warm-up ticks, then the region of EXACTLY K ticks bracketed by barrier + synchronize on both
+           sides, max over ranks.  The region is repeated (`repeats`) until at least --min-time seconds have been
+           timed; `ms_per_step` / `value` are the MEDIAN repeat (a 20-tick region is 1 ms: one sample of it is noise)
+  N > 1  : cascades/tiles are independent units: every rank owns its own C cascades (weak scaling,
+           no data-path collective).  The finished maps are gathered over RCCL by sharding.MapGatherer: owned layers
+           only, from a snapshot, on a side stream -- once after the timed region ("final gather"), or every k ticks
+           inside it with --gather-every k (then the rate without any gather is measured and reported beside it).
+  sweep  : --sweep appends one line per BASELINE configuration (256^2 x 4, 1024^2 x {1,4,8}, 2048^2 x 4), each with its
+           own roofline and CPU baseline, to --sweep-out (profiles/) and prints the headline line last.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -16,19 +22,29 @@ Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
 """
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
-# algorithmic bytes per texel per cascade-update: pass 1 reads h0 (16) and writes the
-# FP32 intermediate (32); pass 2 reads it (32), reads the previous normal texel for foam (8) and writes
-# the two RGBA16F maps (8 + 8).  (The 4 B/texel omega plane pass 1 also reads is NOT counted.)
-BYTES_PASS1, BYTES_PASS2 = 48, 56
-BYTES_MAP = BYTES_PASS1 + BYTES_PASS2  # 104
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+COPY_CEILING_GBPS = 6290.0  # the same guide's measured copy rate (profiles/r01_membench_copy_ceiling.txt reproduces it)
+# SURVEY.md 8d's contract: algorithmic bytes per texel per cascade-update of a two-pass transform with a four-layer FP32
+# intermediate -- pass 1 reads h0 (16) and writes the intermediate (32); pass 2 reads it (32), reads the previous normal
+# texel for foam (8) and writes the two RGBA16F maps (8 + 8).
+CONTRACT_BYTES = (48, 56)
+# Bytes per texel the LAUNCHED kernel family must move, (pass 1, pass 2):
+#   four-layer intermediate:  h0(k) 8 + omega 4 read, T 32 written | T 32 + foam 2 read, maps 16 + foam 2 written
+#   compact intermediate   :  h0(k) 8 + omega 4 read, T 20 written | T 20 + foam 2 read, maps 16 + foam 2 written
+# (the redundant half of the reference's spectrum texel is never stored, foam is a private FP16 plane; PMC counters put
+#  the memory-side traffic within 1-2 % of these: profiles/pmc_traffic.json)
+FAMILY_BYTES = {"standard": (44, 52), "layer_parallel": (44, 52), "compact": (32, 40), "layer_parallel_compact": (32, 40)}
+SUFFIX = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}
+SWEEP = [(256, 4), (1024, 1), (1024, 8), (2048, 4), (1024, 4)]  # BASELINE.json configs C2, C3', C4 (per node), C5, C3 (headline last)
 
 
 def parse():
@@ -38,7 +54,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--map-size", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4, help="cascades per GPU")
-    ap.add_argument("--gather-every", type=int, default=0, help="RCCL all_gather of the maps every k ticks inside the timed region (0 = once, after it)")
+    ap.add_argument("--min-time", type=float, default=0.5, help="repeat the K-tick timed region until this many seconds have been timed (median reported)")
+    ap.add_argument("--max-repeats", type=int, default=500)
+    ap.add_argument("--gather-every", type=int, default=0, help="gather the maps every k ticks inside the timed region (0 = once, after it)")
+    ap.add_argument("--gather", choices=("all", "root"), default="all", help="all_gather to every rank, or gather to rank 0 (the consumer GPU)")
+    ap.add_argument("--no-overlap", action="store_true", help="serialise each gather with the compute stream (for comparison; default: side stream)")
     ap.add_argument("--prime-ms", type=float, default=300.0,
                     help="untimed clock priming before the W warm-up steps: the chip's DVFS needs tens of ms of load to reach its "
                          "steady clock, and a short run would otherwise time the ramp (0 disables)")
@@ -46,11 +66,13 @@ def parse():
                                                      "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (numbers are meaningless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline sample size in ticks (0 = auto, ~10-20 s)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample size in seconds of host work")
+    ap.add_argument("--sweep", action="store_true", help="one line per BASELINE configuration, appended to --sweep-out")
+    ap.add_argument("--sweep-out", default=os.path.join(ROOT, "profiles", "sweep.jsonl"))
     return ap.parse_args()
 
 
-def cpu_baseline(n, cascades):
+def cpu_baseline(n, cascades, seconds):
     """The oracle in reference-structure mode (separate modulate / table-driven radix-2 Stockham rows /
     transpose / rows / unpack passes = the reference's own algorithm) timed on this host's cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -63,7 +85,7 @@ def cpu_baseline(n, cascades):
     t0 = time.perf_counter()
     g.update_all(UPDATE_DELTA)
     one = time.perf_counter() - t0
-    frames = max(1, min(200, int(12.0 / max(one, 1e-3))))
+    frames = max(1, min(400, int(seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(frames):
         g.update_all(UPDATE_DELTA)
@@ -72,6 +94,200 @@ def cpu_baseline(n, cascades):
     g.close()
     return {"value": round(frames * cascades / dt, 3), "unit": "maps/s", "cores": cores, "kind": "port",
             "sample": f"{frames} ticks of {n}^2 x {cascades} cascades (oracle, OpenMP x{cores}, {dt:.1f} s)"}
+
+
+def pmc_traffic(kernel, n, per_launch):
+    """memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (NOT measured by this run)"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    key = f"{kernel}_{n}x{per_launch}"
+    return table.get(key) if float(per_launch).is_integer() or isinstance(per_launch, int) else None
+
+
+def measure(args, torch, dist, world, rank, local_rank, n, C):
+    from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
+    from godotoceanwaves_amd import sharding
+
+    layers = max(2, C)
+    # The generator enqueues on a torch-owned stream and writes into torch-owned device memory, so that snapshots and RCCL
+    # are ordered against it by ordinary stream semantics (PyTorch = memory + streams + collectives plumbing).
+    compute = torch.cuda.Stream()
+    disp = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
+    norm = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
+    torch.cuda.synchronize()
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.device_id = local_rank
+    gen.stream = compute.cuda_stream
+    gen.external_maps = (disp.data_ptr(), norm.data_ptr())
+    gen.init_gpu(layers)
+    # global cascade ids: rank r owns cascades r*C .. r*C+C-1 (independent units; presets repeat with new seeds)
+    params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
+    gat = None
+    if world > 1:
+        gat = sharding.MapGatherer(torch, dist, world, rank, disp, norm, C, mode=args.gather, root=0,
+                                   overlap=not args.no_overlap, compute_stream=compute)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def region(gather_every):
+        """exactly K ticks, barrier + synchronize on both sides; returns max-over-ranks seconds"""
+        sync_all()
+        t0 = time.perf_counter()
+        if gat is not None and gather_every > 0:
+            done = 0
+            while done < args.steps:
+                k = min(gather_every, args.steps - done)
+                gen.run(UPDATE_DELTA, params, k)
+                gat.begin()
+                done += k
+            gat.wait()  # the last gather's bytes have arrived
+        else:
+            gen.run(UPDATE_DELTA, params, args.steps)
+        sync_all()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def timed(gather_every):
+        first = region(gather_every)
+        repeats = max(1, min(args.max_repeats, int(math.ceil(args.min_time / max(first, 1e-6)))))
+        samples = [first] + [region(gather_every) for _ in range(repeats - 1)]
+        return statistics.median(samples), samples
+
+    # ---- warm-up (includes the one-time spectrum generation) ----
+    t_spec0 = time.perf_counter()
+    gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    spectrum_ms = (time.perf_counter() - t_spec0) * 1e3
+    prime_ticks = 0
+    if args.prime_ms > 0:  # untimed: bring the clocks to their steady state (not part of W or K)
+        tp = time.perf_counter()
+        while (time.perf_counter() - tp) * 1e3 < args.prime_ms:
+            gen.run(UPDATE_DELTA, params, 50)
+            gen.sync()
+            prime_ticks += 50
+    if args.warmup > 1:
+        gen.run(UPDATE_DELTA, params, args.warmup - 1)
+    if gat is not None:
+        gat.begin()
+        gat.wait()
+
+    # ---- timed regions ----
+    elapsed, samples = timed(args.gather_every if world > 1 else 0)
+    no_gather = None
+    if world > 1 and args.gather_every > 0:
+        no_gather, _ = timed(0)
+
+    # ---- final gather (outside the timed region unless --gather-every) + sanity ----
+    gather_ms = None
+    if gat is not None:
+        sync_all()
+        g0 = time.perf_counter()
+        gat.begin()
+        gat.wait()
+        gather_ms = max_over_ranks(time.perf_counter() - g0) * 1e3
+        got = gat.maps()
+        if got is not None:
+            assert torch.equal(got[0][rank * C:(rank + 1) * C], disp[:C]) and bool(torch.isfinite(got[0].float()).all())
+    assert bool(torch.isfinite(disp[:C].float()).all()) and float(disp[:C].float().abs().max()) > 0.0
+
+    # ---- per-kernel durations, in situ: during `probe` further ticks every launch carries start/stop HIP events bound
+    #      to its own dispatch packet on the generator's stream (hipExtLaunchKernel): begin -> end of the kernel itself,
+    #      the quantity a rocprofv3 kernel trace reports ----
+    gen.timing(True)
+    probe = max(50, min(400, args.steps))
+    gen.run(UPDATE_DELTA, params, probe)
+    gen.sync()
+    p1_ms, p2_ms, launches = gen.timing_read()
+    gen.timing(False)
+    family = gen.last_kernel_family()
+    sync_all()
+    gen.free()
+    if rank != 0:
+        return None
+
+    maps = args.steps * C * world
+    pairs_per_tick = launches / probe                   # the runtime may split a tick into several launch pairs (ow_runtime.hip batch_size)
+    per_launch = C / pairs_per_tick                     # average cascades per launch (7 cascades go as 4 + 3 -> 3.5)
+    per_launch = int(per_launch) if float(per_launch).is_integer() else round(per_launch, 3)
+    texels = n * n * per_launch
+    k1, k2 = FAMILY_BYTES[family]
+    first = p1_ms >= p2_ms
+    dom = ("k_pass1" if first else "k_pass2") + SUFFIX[family]  # the name rocprofv3 lists the kernel under
+    dom_ms = max(p1_ms, p2_ms)
+    dom_bpt, dom_contract = (k1, CONTRACT_BYTES[0]) if first else (k2, CONTRACT_BYTES[1])
+    gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    achieved = gbps(dom_bpt * texels, dom_ms)
+    contract = gbps(dom_contract * texels, dom_ms)
+    tick_s = elapsed / args.steps
+    tick_moved = (k1 + k2) * n * n * C / tick_s / 1e9          # per GPU
+    tick_contract = sum(CONTRACT_BYTES) * n * n * C / tick_s / 1e9
+    traffic = pmc_traffic(dom, n, per_launch)
+    headline = (n, C) == (1024, 4)
+    out = {
+        "metric": "displacement+normal maps/sec, 1024^2 x 4 cascades; achieved HBM GB/s vs peak" if headline else
+                  f"displacement+normal maps/sec, {n}^2 x {C} cascades; achieved HBM GB/s vs peak",
+        "value": round(maps / elapsed, 2),
+        "unit": "maps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(tick_s * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "repeats": len(samples),
+        "ms_per_step_min_max": [round(min(samples) / args.steps * 1e3, 5), round(max(samples) / args.steps * 1e3, 5)],
+        "timed_seconds": round(sum(samples), 4),
+        "config": {"workload": f"{n}^2 x {C} cascades per GPU, steady-state tick (modulate + 2-D IFFT + unpack/foam), "
+                               f"delta=1/50 s, SURVEY 8d cascade table",
+                   "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
+                   "gather": (f"{args.gather}, every {args.gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
+                             if (world > 1 and args.gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
+                   **({"rehearsal": f"backend={args.backend}, share_gpu={args.share_gpu}: NOT a measurement"}
+                      if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
+        "roofline": {
+            "bound": "hbm", "kernel": dom, "kernel_family": family,
+            # bytes this kernel must move (its family's design bytes) / its average launch duration
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "bytes_per_texel": dom_bpt, "bytes_per_launch": int(dom_bpt * texels),
+            "bytes_basis": "bytes the launched kernel family must move (bench.py FAMILY_BYTES, DESIGN.md section 3)",
+            "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBPS, 4), "copy_ceiling": COPY_CEILING_GBPS,
+            # SURVEY 8d's contract bytes (four-layer FP32 intermediate, 104 B/texel per map) over the same duration: a
+            # figure of merit against a design that moves more, NOT a bandwidth (it can exceed the copy ceiling)
+            "contract_bytes_per_texel": dom_contract, "contract_gbps": round(contract, 1), "frac_contract_104": round(contract / HBM_PEAK_GBPS, 4),
+            "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of an earlier visit, NOT measured by this run" if traffic else None,
+            "traffic_gbps": round(gbps(traffic, dom_ms), 1) if traffic else None,
+            "avg_launch_ms": round(dom_ms, 5), "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5),
+            "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
+            "tick": {"bytes_per_texel": k1 + k2, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
+                     "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
+                     "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},
+        },
+        "frames_per_s": round(args.steps * world / elapsed, 2),
+        "spectrum_init_ms": round(spectrum_ms, 3),
+        "clock_priming": {"ms": args.prime_ms, "ticks": prime_ticks},
+    }
+    if gat is not None:
+        out["final_gather_ms"] = round(gather_ms, 3)
+        out["gather_bytes"] = {"sent_per_rank": gat.bytes_sent, "received_rank0": gat.bytes_received}
+    if no_gather is not None:
+        out["no_gather"] = {"ms_per_step": round(no_gather / args.steps * 1e3, 5), "value": round(maps / no_gather, 2)}
+    return out
 
 
 def main():
@@ -96,154 +312,23 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
-    from godotoceanwaves_amd import sharding
-
-    n, C = args.map_size, args.cascades
-    layers = max(2, C)
-    # outputs live in torch-owned device memory so RCCL can gather them (PyTorch = memory + collectives plumbing)
-    disp = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
-    norm = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
-    gen = WaveGenerator()
-    gen.map_size = n
-    gen.device_id = local_rank
-    gen.external_maps = (disp.data_ptr(), norm.data_ptr())
-    gen.init_gpu(layers)
-    # global cascade ids: rank r owns cascades r*C .. r*C+C-1 (independent units; presets repeat with new seeds)
-    params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
-
-    def sync_all():
+    configs = SWEEP if args.sweep else [(args.map_size, args.cascades)]
+    for n, C in configs:
+        out = measure(args, torch, dist, world, rank, local_rank, n, C)
+        if rank == 0:
+            if not args.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline(n, C, args.cpu_seconds if not args.sweep else min(args.cpu_seconds, 8.0))
+                out["gpu_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            line = json.dumps(out)
+            if args.sweep:
+                os.makedirs(os.path.dirname(args.sweep_out), exist_ok=True)
+                with open(args.sweep_out, "a") as f:
+                    f.write(line + "\n")
+            print(line, flush=True)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    gathered = None
-    if world > 1:
-        gathered = sharding.alloc_gather_buffers(torch, world, disp, norm)
-
-    def gather():
-        gen.sync()
-        sharding.gather_maps(dist, gathered, disp, norm)
-
-    # ---- warm-up (includes the one-time spectrum generation) ----
-    t_spec0 = time.perf_counter()
-    gen.update_all(UPDATE_DELTA, params)
-    gen.sync()
-    spectrum_ms = (time.perf_counter() - t_spec0) * 1e3
-    prime_ticks = 0
-    if args.prime_ms > 0:  # untimed: bring the clocks to their steady state (not part of W or K)
-        tp = time.perf_counter()
-        while (time.perf_counter() - tp) * 1e3 < args.prime_ms:
-            gen.run(UPDATE_DELTA, params, 50)
-            gen.sync()
-            prime_ticks += 50
-    if args.warmup > 1:
-        gen.run(UPDATE_DELTA, params, args.warmup - 1)
-    if world > 1:
-        gather()
-    sync_all()
-
-    # ---- timed region: exactly K ticks ----
-    t0 = time.perf_counter()
-    if world > 1 and args.gather_every > 0:
-        done = 0
-        while done < args.steps:
-            k = min(args.gather_every, args.steps - done)
-            gen.run(UPDATE_DELTA, params, k)
-            gather()
-            done += k
-    else:
-        gen.run(UPDATE_DELTA, params, args.steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    # ---- final gather (outside the timed region unless --gather-every) + sanity ----
-    gather_ms = None
-    if world > 1:
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        gather()
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert torch.equal(gathered[0][rank], disp) and bool(torch.isfinite(gathered[0].float()).all())
-    assert bool(torch.isfinite(disp.float()).all()) and float(disp.float().abs().max()) > 0.0
-
-    # ---- per-kernel durations, in situ: during `probe` further ticks every launch carries start/stop HIP events bound
-    #      to its own dispatch packet on the generator's stream (hipExtLaunchKernel): begin -> end of the kernel itself,
-    #      the quantity a rocprofv3 kernel trace reports ----
-    gen.timing(True)
-    probe = max(50, min(400, args.steps))
-    gen.run(UPDATE_DELTA, params, probe)
-    gen.sync()
-    p1_ms, p2_ms, launches = gen.timing_read()
-    gen.timing(False)
-    family = gen.last_kernel_family()
-    suffix = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}[family]
-    per_launch = gen.last_batch_cascades()  # cascades per pair of launches (the runtime may split a tick: ow_runtime.hip batch_size)
-    sync_all()
-
-    if rank == 0:
-        maps = args.steps * C * world
-        texels = n * n * per_launch  # per launch (the runtime batches cascades so that T stays in the Infinity Cache)
-        dom = ("k_pass1" if p1_ms >= p2_ms else "k_pass2") + suffix  # the name rocprofv3 lists the kernel under
-        dom_ms = max(p1_ms, p2_ms)
-        dom_bytes = (BYTES_PASS1 if p1_ms >= p2_ms else BYTES_PASS2) * texels
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        frame_gbps = BYTES_MAP * n * n * maps / elapsed / 1e9 / world  # per-GPU algorithmic GB/s over the whole tick
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get(f"{dom}_{n}x{per_launch}")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "displacement+normal maps/sec, 1024^2 x 4 cascades; achieved HBM GB/s vs peak",
-            "value": round(maps / elapsed, 2),
-            "unit": "maps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{n}^2 x {C} cascades per GPU, steady-state tick (modulate + 2-D IFFT + unpack/foam), "
-                                   f"delta=1/50 s, SURVEY 8d cascade table",
-                       "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
-                       "gather": ("every %d ticks (timed)" % args.gather_every) if (world > 1 and args.gather_every) else
-                                 ("final, untimed" if world > 1 else "none"),
-                       **({"rehearsal": f"backend={args.backend}, share_gpu={args.share_gpu}: NOT a measurement"}
-                          if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_family": family, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         # what really crossed the memory interface per second (PMC bytes / this run's launch time): the compact
-                         # kernels move fewer bytes than SURVEY 8d's algorithmic 104 B/texel, so `achieved` can exceed it
-                         "traffic_gbps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if (traffic and dom_ms > 0) else None,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
-                         "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5), "launches_timed": launches,
-                         "cascades_per_launch": per_launch,
-                         "tick_achieved_gbps_per_gpu": round(frame_gbps, 1), "tick_frac": round(frame_gbps / HBM_PEAK_GBPS, 4)},
-            "frames_per_s": round(args.steps * world / elapsed, 2),
-            "spectrum_init_ms": round(spectrum_ms, 3),
-            "clock_priming": {"ms": args.prime_ms, "ticks": prime_ticks},
-        }
-        if gather_ms is not None:
-            out["final_gather_ms"] = round(gather_ms, 3)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, C)
-            out["gpu_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -43,6 +43,9 @@ SIGNATURES = {
     "ow_destroy": (None, [C.c_void_p]),
     "ow_cascade_params_default": (None, [_P(ow_cascade_params)]),
     "ow_update": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
+    "ow_set_cascade_params": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_cascade_params)]),
+    "ow_get_cascade_params": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_cascade_params)]),
+    "ow_debug_inject_fault": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ow_process": (C.c_int, [C.c_void_p]),
     "ow_update_all": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
     "ow_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),

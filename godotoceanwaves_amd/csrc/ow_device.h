@@ -498,8 +498,12 @@ struct CascadeFrame {
     float foam_grow_rate;
     float foam_decay;      // expf(-foam_decay_rate), evaluated once on the host (fft_unpack.glsl:62)
     int32_t cascade;       // which array layer / spectrum slot this launch slot works on
-    int32_t pad0;
+    int32_t fault;         // entry 0 only: fault-injection bits of this batch (ow_debug_inject_fault; 0 in normal operation)
 };
+// bits of the device status word (DeviceBuffers::status): set by a kernel, turned into OW_ERR_HIP by the host at the next sync
+constexpr uint32_t kStatusRowSyncTimeout = 1u;  // a wave-pair rendezvous (RowSync, N = 2048) gave up waiting for its partner
+// fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch
+constexpr int32_t kFaultRowSync = 1;
 constexpr int kMaxCascades = 8;
 struct FrameArgs {
     CascadeFrame c[kMaxCascades];

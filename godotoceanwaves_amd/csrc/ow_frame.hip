@@ -45,7 +45,7 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
     }
     if constexpr (plan_T(N) >= 16) {
         if (fam == 4) {
-            launch(k_pass1c_lp<N>, dim3(blocks, 6), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            launch(k_pass1c_lp<N>, dim3(blocks, 6), dim3(plan_wg_threads(N)), s, lt, buf, args, (Stamp *)nullptr);
             return hipGetLastError();
         }
     }
@@ -65,8 +65,8 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
         const int lp_blocks = slots * (N / plan_lp_rows(N));
         if constexpr (plan_T(N) >= 16) {
             if (fam == 4) {
-                if (buf.f32) launch(k_pass2c_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
-                else launch(k_pass2c_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args);
+                if (buf.f32) launch(k_pass2c_lp<N, true>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, (Stamp *)nullptr);
+                else launch(k_pass2c_lp<N, false>, dim3(lp_blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, (Stamp *)nullptr);
                 return hipGetLastError();
             }
         }

@@ -56,6 +56,9 @@ struct RowSync {
     typedef __attribute__((address_space(3))) int lds_int;
     volatile lds_int *mine = nullptr, *partner = nullptr;
     int epoch = 0;
+    uint32_t *status = nullptr;  // device status word: a rendezvous that gives up says so there (never silently)
+    bool mute = false;           // fault injection: this wave never publishes (tests only)
+    bool dead = false;           // a rendezvous already timed out: no further waiting in this kernel
     // flags: two ints per pair (zeroed by init_row_sync); pair = index of the row (or row x layer) inside the block
     __device__ __forceinline__ void attach(int *flags, int pair, int wave_in_pair) {
         if constexpr (plan_row_spans_waves(N)) {
@@ -63,13 +66,31 @@ struct RowSync {
             partner = (volatile lds_int *)(flags + 2 * pair + (wave_in_pair ^ 1));
         }
     }
+    __device__ __forceinline__ void watch(uint32_t *status_word, int fault) {
+        if constexpr (plan_row_spans_waves(N)) {
+            status = status_word;
+            mute = (fault & kFaultRowSync) != 0 && ((threadIdx.x / 64) & 1) != 0;
+        }
+    }
     __device__ __forceinline__ void sync() {
         if constexpr (plan_row_spans_waves(N)) {
             ++epoch;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // s_waitcnt lgkmcnt(0): my LDS reads/writes are done
-            *mine = epoch;
-            // bounded: a partner that never arrives (a bug) must not hang the device; ~2^20 polls is >100 ms
-            for (int spin = 0; __builtin_amdgcn_readfirstlane(*partner) < epoch && spin < (1 << 20); ++spin) __builtin_amdgcn_s_sleep(1);
+            if (!mute) *mine = epoch;
+            // bounded: a partner that never arrives (a bug) must not hang the device; 2^18 polls of >= 64 clocks is > 5 ms, three
+            // orders of magnitude beyond the kernel's whole duration.  Giving up is REPORTED: the status word makes the next
+            // ow_sync fail, the results of this batch are garbage.
+            if (!dead) {
+                int spin = 0;
+                while (__builtin_amdgcn_readfirstlane(*partner) < epoch && spin < (1 << 18)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spin;
+                }
+                if (spin == (1 << 18)) {
+                    dead = true;
+                    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, kStatusRowSyncTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         } else {
             wave_sync();
@@ -89,6 +110,34 @@ __device__ __forceinline__ unsigned xcc_id() {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 0xf;
 }
+// per-wave cycle stamps of the small-batch kernels (tools/kbench_small only; the product instantiates STAMPS = false)
+template <bool STAMPS>
+struct WaveStamps {
+    unsigned long long ts[STAMPS ? 16 : 1] = {0};
+    __device__ __forceinline__ void at(int k, float keep) {
+        if constexpr (STAMPS) {
+            asm volatile("" ::"v"(keep));
+            ts[k] = __builtin_readcyclecounter();
+        }
+    }
+    __device__ __forceinline__ void write(Stamp *stamps, int waves_per_block, unsigned long long tag) {
+        if constexpr (STAMPS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ts[14] = __builtin_readcyclecounter();
+            ts[15] = tag;
+            if ((threadIdx.x & 63) == 0) {
+                Stamp st;
+                for (int k = 0; k < 16; ++k) st.t[k] = ts[k];
+                unsigned v;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+                st.xcc = v & 0xf;
+                st.pad = 0;
+                stamps[(blockIdx.y * gridDim.x + blockIdx.x) * waves_per_block + threadIdx.x / 64] = st;
+            }
+        }
+    }
+};
+
 #define OW_STAMP(k, keep)                          \
     if constexpr ((VAR & 8) != 0) {                \
         asm volatile("" ::"v"(keep));              \
@@ -212,6 +261,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
@@ -310,6 +360,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
     constexpr bool kFft = (VAR & 4) == 0;
     constexpr bool kStore = (VAR & 2) == 0;
@@ -426,6 +477,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
 
     int slot, row0;
@@ -539,6 +591,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
 
     int slot, row0;
@@ -633,6 +686,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
     const int L = blockIdx.y;
     int slot, row0;
@@ -703,6 +757,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, ROWS * kLayers);
 
     TwPrefetch<N> twp;
@@ -741,8 +796,10 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
 // Pass 1: grid (rows/8, 6); y = 0..2 the compact layers (lower-half blocks of layer 1 leave at once), y = 3..5 the three extra
 // transforms of texel row 0 (only the block that owns row 0 stays).  Pass 2: the four lane groups of a row compute F0..F3.
 // ===================================================================================================
-template <int N, int AUX_T = kAuxDefault>
-__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffers buf, FrameArgs args) {
+template <int N, int AUX_T = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+    WaveStamps<STAMPS> ws;
+    ws.at(0, 0.0f);
     constexpr int Tn = plan_T(N), P = kP;
     static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
     int slot, row0;
@@ -760,6 +817,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
     int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, rw, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, kWgRows);
     const CascadeFrame cf = args.c[slot];
     const int y = row0 + rw;
@@ -775,9 +833,13 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
         cplx a[P], b[P];
         float om[P];
         Pass1<N>::load_raw(a, b, om, t, y, h0_c, om_c);
+        ws.at(1, 0.0f);                 // loads issued
         tw_commit<N>(twp, tw_lds);
+        ws.at(2, tw_lds[0].x);          // table in LDS, block barrier passed
+        ws.at(3, a[15].x + om[15]);     // the wave's own data has arrived
         Pass1<N>::modulate(h, a, b, om, cf.time);
     }
+    ws.at(4, h[15].x);                  // modulated
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
@@ -794,22 +856,30 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
         default: Pass1<N>::template row0_input<3>(d, h, ik, t, ky, dkx); break;
     }
     OW_SCHED_FENCE();
+    ws.at(5, d[15].x);                  // layer input built
     row_ifft<N>(d, t, lds_row, tw_lds, rs);
+    ws.at(6, d[15].x);                  // transformed
     if (L >= 3) {  // straight to the side buffer, lanes of row 0 only (the other rows of the block computed nothing of use)
         if (y == 0) {
 #pragma unroll
             for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)(L - 2) * 8u, d[OutMap<N>::slot_of(o)]);
         }
+        ws.write(stamps, (plan_wg_threads(N) + 63) / 64, (unsigned long long)L);
         return;
     }
     rs.sync();
     Pass1<N>::stage_write(d, t, lds_row);
     lds_barrier();
+    ws.at(7, 0.0f);                     // staged, block barrier passed
     Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
+    ws.at(8, 0.0f);                     // stores issued
+    ws.write(stamps, (plan_wg_threads(N) + 63) / 64, (unsigned long long)L);   // [14] = stores acknowledged
 }
 
-template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
-__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffers buf, FrameArgs args) {
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+    WaveStamps<STAMPS> ws;
+    ws.at(0, 0.0f);
     constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
     static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
     __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + plan_sync_flag_cplx(N, plan_lp_rows(N) * kLayers)];
@@ -836,6 +906,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
     RowSync<N> rs;
     rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
     init_row_sync<N>(sync_flags, ROWS * kLayers);
 
     TwPrefetch<N> twp;
@@ -852,8 +923,12 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     }
     if (g != 0) Pass2<N>::put_row0(d, t, gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
     const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
+    ws.at(1, 0.0f);                     // loads issued
     tw_commit<N>(twp, tw_lds);
+    ws.at(2, tw_lds[0].x);              // table in LDS, block barrier passed
+    ws.at(3, d[15].x + foam_bits.x);    // the wave's own data has arrived
     row_ifft<N>(d, t, region(r, g), tw_lds, rs);
+    ws.at(6, d[15].x);                  // transformed
     rs.sync();
     {
         cplx *mine = region(r, g);
@@ -861,6 +936,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
         for (int o = 0; o < P; ++o) mine[t + Tn * o] = d[OutMap<N>::slot_of(o)];
     }
     lds_barrier();
+    ws.at(7, 0.0f);                     // all four transforms of the row are in LDS
     const float fb0 = foam_bits.x, fb1 = foam_bits.y;
     const uint32_t fpk[2] = {__builtin_bit_cast(uint32_t, fb0), __builtin_bit_cast(uint32_t, fb1)};
     uint32_t fnew[2] = {0u, 0u};
@@ -877,6 +953,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     }
     const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
     gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
+    ws.at(8, 0.0f);                     // unpacked, stores issued
+    ws.write(stamps, (plan_lp_threads(N) + 63) / 64, (unsigned long long)g);   // [14] = stores acknowledged
 }
 
 

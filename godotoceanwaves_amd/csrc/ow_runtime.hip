@@ -55,9 +55,16 @@ struct ow_context {
     bool own_stream = false, own_disp = false, own_norm = false;
     ow::DeviceBuffers buf{};
     ow::cplx *tw_dev = nullptr;
-    // generator state per invocation of update() (wave_generator.gd:13-15)
-    ow_cascade_params *pass_parameters = nullptr;
+    // generator state per invocation of update() (wave_generator.gd:13-15).  The reference keeps a reference to the caller's
+    // Array; a C caller's memory is only borrowed for the duration of a call, so the context keeps COPIES of the armed records
+    // (ow_set_cascade_params / ow_get_cascade_params are the explicit form of "the parameter objects are live")
+    ow_cascade_params pass_parameters[OW_MAX_CASCADES] = {};
+    int pass_count = 0;
     int pass_num_cascades_remaining = 0;
+    // device status word: page-locked host memory mapped into the device; kernels OR error bits into it (a bounded
+    // device-side spin that gave up), every synchronising entry point turns a non-zero word into OW_ERR_HIP
+    uint32_t *status_host = nullptr;
+    uint32_t inject_fault = 0;  // ow_debug_inject_fault: applied to the next batch only
     // timing: a pool of events so that timed ticks stay enqueued back to back
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 4 per timed batch: start/stop of the pass-1 dispatch, start/stop of the pass-2 dispatch
@@ -131,25 +138,52 @@ ow_status next_events(ow_context *c, hipEvent_t **out) {
     return OW_OK;
 }
 
+// hipStreamSynchronize + the device status word
+ow_status sync_stream(ow_context *c) {
+    OW_HIP(hipStreamSynchronize(c->stream));
+    if (c->status_host && *c->status_host != 0u) {
+        const uint32_t bits = *c->status_host;
+        *c->status_host = 0u;  // reported once; later batches start clean
+        return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
+                                "the last synchronisation are invalid", bits, (bits & ow::kStatusRowSyncTimeout) ? ": wave-pair rendezvous timed out" : "");
+    }
+    return OW_OK;
+}
+
+bool finite_record(const ow_cascade_params &p) {
+    const float f[] = {p.tile_length[0], p.tile_length[1], p.wind_speed, p.wind_direction, p.fetch_length, p.swell, p.spread, p.detail,
+                       p.whitecap, p.foam_amount};
+    for (float v : f)
+        if (!std::isfinite(v)) return false;
+    return std::isfinite(p.time) && std::isfinite(p.foam_grow_rate) && std::isfinite(p.foam_decay_rate);
+}
+
 // _update() for a batch of cascade indices (wave_generator.gd:65-85)
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
+    // everything is validated before anything is launched: a bad record must not leave the batch half enqueued
     for (int i = 0; i < count; ++i) {
-        ow_cascade_params &p = params[idx[i]];
+        const ow_cascade_params &p = params[idx[i]];
+        if (!finite_record(p)) return fail(OW_ERR_INVALID, "cascade %d: non-finite parameter", idx[i]);
         if (!(p.tile_length[0] > 0.0f) || !(p.tile_length[1] > 0.0f))
             return fail(OW_ERR_INVALID, "cascade %d: tile_length must be positive", idx[i]);
+    }
+    for (int i = 0; i < count; ++i) {
+        ow_cascade_params &p = params[idx[i]];
         if (p.should_generate_spectrum) {  // :68-72
-            const double F = (double)p.fetch_length * 1e3;
+            // the exported setters clamp these two (wave_cascade_parameters.gd:15,20: max(0.0001, value)); a C caller has no setter
+            const float wind_speed = std::max(p.wind_speed, 1e-4f), fetch_length = std::max(p.fetch_length, 1e-4f);
+            const double F = (double)fetch_length * 1e3;
             ow::SpectrumPC pc;
             pc.seed_x = p.spectrum_seed[0];
             pc.seed_y = p.spectrum_seed[1];
             pc.tile_x = p.tile_length[0];
             pc.tile_y = p.tile_length[1];
-            pc.alpha = (float)ow_jonswap_alpha((double)p.wind_speed, F);
-            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency((double)p.wind_speed, F);
-            pc.wind_speed = p.wind_speed;
+            pc.alpha = (float)ow_jonswap_alpha((double)wind_speed, F);
+            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency((double)wind_speed, F);
+            pc.wind_speed = wind_speed;
             pc.angle = (float)((double)p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
             pc.depth = c->depth;
             pc.swell = p.swell;
@@ -174,7 +208,10 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         ow::FrameArgs part;
         std::memset(&part, 0, sizeof(part));
         for (int i = 0; i < nb; ++i) part.c[i] = args.c[b0 + i];
+        part.c[0].fault = (int32_t)c->inject_fault;  // debug hook (ow_debug_inject_fault): this batch only
+        c->inject_fault = 0;
         c->last_args = part;
+        c->last_args.c[0].fault = 0;
         c->last_count = nb;
         c->last_family = ow::kernel_family(c->n, nb, c->kernel_mode);
         for (int &sl : c->slot_of) sl = -1;
@@ -239,9 +276,15 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(OW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
-    int dev = cfg->device_id;
-    if (dev < 0) OW_HIP(hipGetDevice(&dev));
+    int dev = cfg->device_id, caller_dev = 0;
+    OW_HIP(hipGetDevice(&caller_dev));
+    if (dev < 0) dev = caller_dev;
     if (dev >= ndev) return fail(OW_ERR_INVALID, "device_id %d >= device count %d", dev, ndev);
+    // the caller's current device is put back on every way out (a library must not change it behind the caller's back)
+    struct DeviceRestore {
+        int dev;
+        ~DeviceRestore() { (void)hipSetDevice(dev); }
+    } restore{caller_dev};
     OW_HIP(hipSetDevice(dev));
     hipDeviceProp_t prop;
     OW_HIP(hipGetDeviceProperties(&prop, dev));
@@ -299,6 +342,11 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
         OW_ALLOC(c->buf.pcol, slots * c->n * sizeof(ow::cplx));
         OW_ALLOC(c->buf.rrow, slots * c->n * 4 * sizeof(ow::cplx));
     }
+    if (hipHostMalloc((void **)&c->status_host, 64, hipHostMallocMapped) != hipSuccess)
+        return bail(fail(OW_ERR_NOMEM, "hipHostMalloc failed for the device status word"));
+    *c->status_host = 0u;
+    if (hipHostGetDevicePointer((void **)&c->buf.status, c->status_host, 0) != hipSuccess)
+        return bail(fail(OW_ERR_HIP, "hipHostGetDevicePointer failed for the device status word"));
     std::vector<ow::cplx> tw;
     ow::make_twiddles(c->n, tw);
     OW_ALLOC(c->tw_dev, tw.size() * sizeof(ow::cplx));
@@ -320,6 +368,8 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
 
 void ow_destroy(ow_context *c) {
     if (!c) return;
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->buf.h0);
@@ -332,6 +382,7 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->buf.pcol);
     (void)hipFree(c->buf.rrow);
     (void)hipFree(c->tw_dev);
+    if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipFree(c->snap_dev);
     if (c->snap_host) (void)hipHostFree(c->snap_host);
@@ -346,14 +397,16 @@ void ow_destroy(ow_context *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }
 
 ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
     if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
     if (count < 1 || count > c->cascades)  // assert(parameters.size() != 0), :91
         return fail(OW_ERR_INVALID, "count %d outside [1,%d]", count, c->cascades);
+    if (!std::isfinite(delta)) return fail(OW_ERR_INVALID, "delta is not finite");
     OW_HIP(hipSetDevice(c->device));
-    if (c->pass_num_cascades_remaining != 0) {  // :94-98
+    if (c->pass_num_cascades_remaining != 0) {  // :94-98: leftovers of the previous arm, with the previous records
         int idx[OW_MAX_CASCADES];
         for (int i = 0; i < c->pass_num_cascades_remaining; ++i) idx[i] = i;
         ow_status st = enqueue(c, c->pass_parameters, idx, c->pass_num_cascades_remaining);
@@ -366,9 +419,25 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
         p.foam_grow_rate = delta * (double)p.foam_amount * 7.5;
         const double d = 10.0 - (double)p.foam_amount;
         p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
+        c->pass_parameters[i] = p;        // :108 -- a copy: `params` is not touched after this call returns
+        p.should_generate_spectrum = 0;   // consumed: the armed copy carries it until the cascade is processed (:72)
     }
-    c->pass_parameters = params;  // :108
+    c->pass_count = count;
     c->pass_num_cascades_remaining = count;  // :109
+    return OW_OK;
+}
+
+ow_status ow_set_cascade_params(ow_context *c, int32_t index, const ow_cascade_params *p) {
+    if (!c || !p) return fail(OW_ERR_INVALID, "null argument");
+    if (index < 0 || index >= c->pass_count) return fail(OW_ERR_INVALID, "index %d outside the %d records of the last ow_update", index, c->pass_count);
+    c->pass_parameters[index] = *p;
+    return OW_OK;
+}
+
+ow_status ow_get_cascade_params(const ow_context *c, int32_t index, ow_cascade_params *out) {
+    if (!c || !out) return fail(OW_ERR_INVALID, "null argument");
+    if (index < 0 || index >= c->pass_count) return fail(OW_ERR_INVALID, "index %d outside the %d records of the last ow_update", index, c->pass_count);
+    *out = c->pass_parameters[index];
     return OW_OK;
 }
 
@@ -376,9 +445,11 @@ ow_status ow_process(ow_context *c) {  // :56-63
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (c->pass_num_cascades_remaining == 0) return OW_OK;
     OW_HIP(hipSetDevice(c->device));
+    const int idx = c->pass_num_cascades_remaining - 1;
+    ow_status st = enqueue(c, c->pass_parameters, &idx, 1);
+    if (st != OW_OK) return st;               // a cascade that could not be enqueued stays armed
     c->pass_num_cascades_remaining -= 1;
-    const int idx = c->pass_num_cascades_remaining;
-    return enqueue(c, c->pass_parameters, &idx, 1);
+    return OW_OK;
 }
 
 ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
@@ -386,9 +457,15 @@ ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, 
     if (st != OW_OK) return st;
     int idx[OW_MAX_CASCADES];
     for (int i = 0; i < count; ++i) idx[i] = count - 1 - i;  // same order _process would take
-    st = enqueue(c, params, idx, count);
+    st = enqueue(c, c->pass_parameters, idx, count);
     if (st != OW_OK) return st;
     c->pass_num_cascades_remaining = 0;
+    return OW_OK;
+}
+
+ow_status ow_debug_inject_fault(ow_context *c, uint32_t fault_bits) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    c->inject_fault = fault_bits;
     return OW_OK;
 }
 
@@ -409,8 +486,7 @@ int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_casc
 ow_status ow_sync(ow_context *c) {
     if (!c) return fail(OW_ERR_INVALID, "null context");
     OW_HIP(hipSetDevice(c->device));
-    OW_HIP(hipStreamSynchronize(c->stream));
-    return OW_OK;
+    return sync_stream(c);
 }
 
 ow_status ow_get_device_ptrs(ow_context *c, void **disp, void **norm, size_t *stride) {
@@ -428,8 +504,7 @@ ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {
     const size_t bytes = plane(c) * sizeof(ow::u16x4);
     if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
     if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
-    return OW_OK;
+    return sync_stream(c);
 }
 
 ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
@@ -437,14 +512,32 @@ ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
     if (mask == 0 || (mask >> c->layers) != 0) return fail(OW_ERR_INVALID, "cascade_mask 0x%x selects no layer or one >= %d", mask, c->layers);
     OW_HIP(hipSetDevice(c->device));
     const size_t pl = plane(c), L = (size_t)c->layers, bytes = pl * sizeof(ow::u16x4);
-    if (!c->copy_stream) {  // first use: second stream, snapshot planes, page-locked staging, events
-        OW_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        if (hipMalloc((void **)&c->snap_dev, 2 * L * bytes) != hipSuccess) return fail(OW_ERR_NOMEM, "hipMalloc of %zu bytes failed for the readback snapshot", 2 * L * bytes);
-        if (hipHostMalloc((void **)&c->snap_host, 2 * L * bytes, hipHostMallocDefault) != hipSuccess)
-            return fail(OW_ERR_NOMEM, "hipHostMalloc of %zu bytes failed for the readback staging", 2 * L * bytes);
+    if (!c->snap_host) {  // first use: second stream, snapshot planes, page-locked staging, events -- committed only when ALL succeeded
+        hipStream_t cs = nullptr;
+        ow::u16x4 *sd = nullptr, *sh = nullptr;
+        hipEvent_t ready[OW_MAX_CASCADES] = {}, done[OW_MAX_CASCADES] = {};
+        bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&sd, 2 * L * bytes) == hipSuccess &&
+                  hipHostMalloc((void **)&sh, 2 * L * bytes, hipHostMallocDefault) == hipSuccess;
+        for (size_t i = 0; ok && i < L; ++i)
+            ok = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            const hipError_t e = hipGetLastError();
+            for (auto &x : ready)
+                if (x) (void)hipEventDestroy(x);
+            for (auto &x : done)
+                if (x) (void)hipEventDestroy(x);
+            if (sh) (void)hipHostFree(sh);
+            (void)hipFree(sd);
+            if (cs) (void)hipStreamDestroy(cs);
+            return fail(OW_ERR_NOMEM, "readback resources (2 x %zu bytes, device + page-locked host) could not be created: %s", 2 * L * bytes, hipGetErrorString(e));
+        }
+        c->copy_stream = cs;
+        c->snap_dev = sd;
+        c->snap_host = sh;
         for (size_t i = 0; i < L; ++i) {
-            OW_HIP(hipEventCreateWithFlags(&c->snap_ready[i], hipEventDisableTiming));
-            OW_HIP(hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+            c->snap_ready[i] = ready[i];
+            c->copy_done[i] = done[i];
         }
     }
     for (int i = 0; i < c->layers; ++i) {
@@ -472,6 +565,7 @@ ow_status ow_readback_wait(ow_context *c, int32_t cascade, const void **disp, co
     OW_HIP(hipSetDevice(c->device));
     OW_HIP(hipEventSynchronize(c->copy_done[cascade]));
     c->copy_pending[cascade] = false;
+    if (*c->status_host != 0u) return sync_stream(c);  // a frame kernel reported a failure: the bytes that landed are not maps
     const size_t pl = plane(c), L = (size_t)c->layers;
     if (disp) *disp = c->snap_host + (size_t)cascade * pl;
     if (norm) *norm = c->snap_host + (L + cascade) * pl;
@@ -505,8 +599,7 @@ ow_status ow_sample_surface(ow_context *c, const float *xz, int32_t count, const
     OW_HIP(hipMemcpyAsync(c->query_xz, xz, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     OW_HIP(ow::launch_sample_surface(c->n, num_cascades, c->buf, c->query_xz, count, sc, c->query_out, c->stream));
     OW_HIP(hipMemcpyAsync(out, c->query_out, (size_t)count * sizeof(ow::SurfaceSample), hipMemcpyDeviceToHost, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
-    return OW_OK;
+    return sync_stream(c);
 }
 
 ow_status ow_set_normal_map(ow_context *c, int32_t cascade, const void *norm) {
@@ -534,8 +627,7 @@ ow_status ow_get_maps_f32(ow_context *c, int32_t cascade, float *out) {
     if (!out) return fail(OW_ERR_INVALID, "null output");
     OW_HIP(hipSetDevice(c->device));
     OW_HIP(hipMemcpyAsync(out, c->buf.f32 + cascade * plane(c) * 8, plane(c) * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
-    return OW_OK;
+    return sync_stream(c);
 }
 
 ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omega) {
@@ -597,18 +689,24 @@ ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (reps < 1 || c->last_count < 1) return fail(OW_ERR_STATE, "nothing has been launched yet (or reps < 1)");
     OW_HIP(hipSetDevice(c->device));
-    hipEvent_t e[3];
-    for (auto &x : e) OW_HIP(hipEventCreate(&x));
-    OW_HIP(hipEventRecord(e[0], c->stream));
-    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
-    OW_HIP(hipEventRecord(e[1], c->stream));
-    for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
-    OW_HIP(hipEventRecord(e[2], c->stream));
-    OW_HIP(hipEventSynchronize(e[2]));
+    hipEvent_t e[3] = {};
     float a = 0, b = 0;
-    OW_HIP(hipEventElapsedTime(&a, e[0], e[1]));
-    OW_HIP(hipEventElapsedTime(&b, e[1], e[2]));
-    for (auto &x : e) (void)hipEventDestroy(x);
+    auto run = [&]() -> ow_status {
+        for (auto &x : e) OW_HIP(hipEventCreate(&x));
+        OW_HIP(hipEventRecord(e[0], c->stream));
+        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
+        OW_HIP(hipEventRecord(e[1], c->stream));
+        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
+        OW_HIP(hipEventRecord(e[2], c->stream));
+        OW_HIP(hipEventSynchronize(e[2]));
+        OW_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+        OW_HIP(hipEventElapsedTime(&b, e[1], e[2]));
+        return OW_OK;
+    };
+    const ow_status st = run();
+    for (auto &x : e)
+        if (x) (void)hipEventDestroy(x);  // on every way out
+    if (st != OW_OK) return st;
     if (p1_ms) *p1_ms = a / reps;
     if (p2_ms) *p2_ms = b / reps;
     if (cascades_per_launch) *cascades_per_launch = c->last_count;

@@ -76,11 +76,6 @@ class WaveCascadeParameters:
         c.should_generate_spectrum = 1 if self.should_generate_spectrum else 0
         c.time, c.foam_grow_rate, c.foam_decay_rate = self.time, self.foam_grow_rate, self.foam_decay_rate
 
-    def _unpack_runtime(self, c):
-        # fields the generator mutates inside the parameter object (wave_generator.gd:72,103-106)
-        self.time, self.foam_grow_rate, self.foam_decay_rate = c.time, c.foam_grow_rate, c.foam_decay_rate
-        self.should_generate_spectrum = bool(c.should_generate_spectrum)
-
 
 class _Descriptor:
     """stand-in for RenderingContext.Descriptor (render_context.gd:23-28): `.rid` is the device pointer"""
@@ -102,7 +97,6 @@ class WaveGenerator:
         self.context = None        # :9  (ow_context*)
         self.descriptors = {}      # :11
         self.pass_parameters = []  # :14
-        self._pass_c = None
         self._lib = None
         self.depth = DEPTH
         self.debug_f32 = False
@@ -141,42 +135,50 @@ class WaveGenerator:
         if not self.context or self.pass_num_cascades_remaining == 0:
             return
         idx = self.pass_num_cascades_remaining - 1
-        self.pass_parameters[idx]._pack(self._pass_c[idx])       # parameter objects are live in the reference
+        self._push_live(idx)                                      # parameter objects are live in the reference
         _lib.check(self._lib.ow_process(self.context))
-        self.pass_parameters[idx]._unpack_runtime(self._pass_c[idx])
+        self.pass_parameters[idx].should_generate_spectrum = False  # :72
+
+    def _push_live(self, idx):
+        """the context holds a COPY of the armed records (a C caller's memory is borrowed during a call only); the reference
+        reads the live object when it processes a cascade, so the object's current fields are pushed right before"""
+        c = ow_cascade_params()
+        self.pass_parameters[idx]._pack(c)
+        _lib.check(self._lib.ow_set_cascade_params(self.context, idx, C.byref(c)))
 
     # ---- update (:90-109) ------------------------------------------------------------------------------
-    def _arm(self, fn, delta, parameters):
+    def _arm(self, fn, delta, parameters, drains_all):
         assert len(parameters) != 0                               # :91
         if not self.context:
             self.init_gpu(max(2, len(parameters)))                # :92-93
-        if self.pass_num_cascades_remaining:                      # leftovers see the live parameter objects
-            for i in range(self.pass_num_cascades_remaining):
-                self.pass_parameters[i]._pack(self._pass_c[i])
-        prev_py, prev_c, prev_rem = self.pass_parameters, self._pass_c, self.pass_num_cascades_remaining
+        leftovers = self.pass_parameters[:self.pass_num_cascades_remaining]
+        for i in range(len(leftovers)):                           # the flush (:94-98) sees the live parameter objects
+            self._push_live(i)
         new_c = (ow_cascade_params * len(parameters))()
         for p, c in zip(parameters, new_c):
             p._pack(c)
+            if any(p is q for q in leftovers):                    # flushed by this very call: its spectrum is regenerated there (:72)
+                c.should_generate_spectrum = 0
         _lib.check(fn(self.context, float(delta), new_c, len(parameters)))
-        for i in range(prev_rem):
-            prev_py[i]._unpack_runtime(prev_c[i])
-            if prev_py[i] in parameters:                          # flushed cascade is also in the new set: keep it clean
-                new_c[parameters.index(prev_py[i])].should_generate_spectrum = 0
-        for p, c in zip(parameters, new_c):
-            p._unpack_runtime(c)
-        self.pass_parameters, self._pass_c = list(parameters), new_c
+        for q in leftovers:
+            q.should_generate_spectrum = False
+        for p, c in zip(parameters, new_c):                       # time and the foam rates advance inside the objects (:103-106)
+            p.time, p.foam_grow_rate, p.foam_decay_rate = c.time, c.foam_grow_rate, c.foam_decay_rate
+            if drains_all:
+                p.should_generate_spectrum = False
+        self.pass_parameters = list(parameters)
 
     def update(self, delta, parameters):
-        self._arm(self._lib.ow_update if self._lib else _lib.load().ow_update, delta, parameters)
+        self._arm(self._lib.ow_update if self._lib else _lib.load().ow_update, delta, parameters, False)
 
     def update_all(self, delta, parameters):
         """throughput mode (not in the reference): update() + every cascade in one pair of launches"""
-        self._arm(self._lib.ow_update_all if self._lib else _lib.load().ow_update_all, delta, parameters)
+        self._arm(self._lib.ow_update_all if self._lib else _lib.load().ow_update_all, delta, parameters, True)
 
     def run(self, delta, parameters, frames):
         """throughput mode: `frames` update_all() ticks enqueued back to back by the C runtime"""
         fn = self._lib.ow_run if self._lib else _lib.load().ow_run
-        self._arm(lambda ctx, d, arr, cnt: fn(ctx, d, arr, cnt, int(frames)), delta, parameters)
+        self._arm(lambda ctx, d, arr, cnt: fn(ctx, d, arr, cnt, int(frames)), delta, parameters, True)
 
     # ---- teardown (:111-113) -------------------------------------------------------------------------------
     def free(self):
@@ -202,6 +204,10 @@ class WaveGenerator:
     # ---- host read-back helpers (RenderingDevice.texture_get_data equivalents) ------------------------------
     def sync(self):
         _lib.check(self._lib.ow_sync(self.context))
+
+    def debug_inject_fault(self, bits):
+        """test hook (ow_debug_inject_fault): fault bits for the next batch only"""
+        _lib.check(self._lib.ow_debug_inject_fault(self.context, int(bits)))
 
     def get_maps(self, cascade):
         n = self.map_size

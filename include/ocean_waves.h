@@ -24,29 +24,32 @@ extern "C" {
 #endif
 
 #define OW_MAX_CASCADES 8 /* MAX_CASCADES, assets/shaders/spatial/water.gdshader:8 */
-#define OW_ABI_VERSION 1
+#define OW_ABI_VERSION 2 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word */
 
 typedef enum ow_status {
     OW_OK = 0,
     OW_ERR_INVALID = 1,   /* bad argument (reference: assert, wave_generator.gd:91, render_context.gd:77) */
     OW_ERR_NO_DEVICE = 2, /* no HIP device / wrong architecture */
-    OW_ERR_HIP = 3,       /* a HIP runtime call failed; see ow_last_error() */
+    OW_ERR_HIP = 3,       /* a HIP runtime call failed, or a frame kernel reported a device-side failure through the
+                             context's status word (found at the next synchronising call); see ow_last_error() */
     OW_ERR_NOMEM = 4,
     OW_ERR_STATE = 5      /* call order violated (e.g. ow_process with nothing armed is NOT an error: it is a no-op) */
 } ow_status;
 
 /* WaveCascadeParameters -- assets/water/wave_cascade_parameters.gd:7-42.
- * Field meaning, units and defaults are the reference's; GDScript floats are FP64 and are narrowed
- * to FP32 when packed into push constants (assets/render_context.gd:131-134), so the FP32 fields
- * here lose nothing.  `time`, `foam_*_rate` and `should_generate_spectrum` are runtime state that
- * the generator mutates inside the caller's struct, exactly as wave_generator.gd:72,103-106 does. */
+ * Field meaning, units and defaults are the reference's.  GDScript floats are FP64 and are narrowed to FP32 when
+ * packed into push constants (assets/render_context.gd:131-134); the exported parameters are FP32 here, i.e. narrowed
+ * one step earlier: the JONSWAP alpha / peak frequency and the degree -> radian conversion are evaluated in FP64 from
+ * the FP32 fields, which can differ from the reference's FP64-input evaluation in the last FP32 bit (inside the tested
+ * tolerance; not bit-exact).  `time`, `foam_*_rate` and `should_generate_spectrum` are runtime state: ow_update
+ * advances them inside the caller's struct (wave_generator.gd:103-106) during the call. */
 typedef struct ow_cascade_params {
     float tile_length[2];     /* metres covered by the tile, default (50, 50)              :7  */
     float displacement_scale; /* consumer-side only, default 1.0                           :9  */
     float normal_scale;       /* consumer-side only, default 1.0                           :11 */
-    float wind_speed;         /* m/s, clamped >= 1e-4, default 20                          :15 */
+    float wind_speed;         /* m/s, default 20; values below 1e-4 are used as 1e-4 (the setter's clamp) :15 */
     float wind_direction;     /* degrees, default 0                                        :17 */
-    float fetch_length;       /* km, clamped >= 1e-4, default 550                          :20 */
+    float fetch_length;       /* km, default 550; values below 1e-4 are used as 1e-4          :20 */
     float swell;              /* [0,2], default 0.8                                        :22 */
     float spread;             /* [0,1], default 0.2                                        :25 */
     float detail;             /* [0,1], default 1.0                                        :28 */
@@ -69,7 +72,9 @@ typedef struct ow_config {
     float depth;          /* metres; the reference hard-codes DEPTH = 20.0 (wave_generator.gd:6); <= 0 selects 20 */
     void *stream;         /* hipStream_t to enqueue on; NULL = the context creates its own non-blocking stream */
     void *displacement_map; /* optional caller-owned DEVICE buffer, layers*N*N*8 bytes (RGBA16F); NULL = context allocates */
-    void *normal_map;       /* optional caller-owned DEVICE buffer, same size; its .a channel is the foam state */
+    void *normal_map;       /* optional caller-owned DEVICE buffer, same size.  Both buffers are ZEROED by ow_create (foam
+                               starts from 0); the recurrence re-reads a private FP16 copy of .a, so a saved state is
+                               restored with ow_set_normal_map, never by pre-loading this buffer */
     uint32_t flags;       /* OW_FLAG_* */
 } ow_config;
 
@@ -103,11 +108,24 @@ void ow_cascade_params_default(ow_cascade_params *p);
 
 /* WaveGenerator.update(delta, parameters) (wave_generator.gd:90-109):
  *   1. cascades armed by the previous call and not yet processed are flushed now, indices
- *      0..remaining-1, with the PREVIOUS parameter array (:94-98);
- *   2. for every cascade: time += delta, foam_grow_rate, foam_decay_rate (:101-106);
+ *      0..remaining-1, with the PREVIOUS records (:94-98);
+ *   2. for every cascade: time += delta, foam_grow_rate, foam_decay_rate (:101-106), written into `params`;
  *   3. all `count` cascades are armed (:108-109).
- * `params` is borrowed until the armed cascades are drained (the reference keeps the Array reference). */
+ * The reference keeps a reference to the caller's Array and reads the live objects later; a C caller's memory is
+ * only borrowed DURING this call: the context keeps a COPY of the `count` records (a managed caller pins its array for
+ * the call and no longer).  `should_generate_spectrum` is consumed: the armed copy carries it until the cascade is
+ * processed, and it is cleared in `params`, so an unchanged array does not regenerate its spectra every tick.  A record
+ * with a non-finite field or a non-positive tile_length is refused with OW_ERR_INVALID when its cascade is enqueued;
+ * nothing of that batch is launched. */
 ow_status ow_update(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
+
+/* "The parameter objects are live" made explicit: replace / read the context's copy of armed record `index`
+ * (0 <= index < count of the last ow_update).  A caller that lets the user edit parameters between ow_update and the
+ * ow_process that consumes them (the reference reads the edited object, wave_generator.gd:56-72) pushes the edited record
+ * with ow_set_cascade_params before that ow_process; ow_get_cascade_params returns the record as the generator left it
+ * (should_generate_spectrum cleared once the cascade has been processed, :72). */
+ow_status ow_set_cascade_params(ow_context *ctx, int32_t index, const ow_cascade_params *params);
+ow_status ow_get_cascade_params(const ow_context *ctx, int32_t index, ow_cascade_params *out);
 
 /* WaveGenerator._process (wave_generator.gd:56-63): processes ONE armed cascade (highest index
  * first) -- the reference's one-cascade-per-rendered-frame load balancing.  No-op when nothing is armed. */
@@ -124,7 +142,11 @@ ow_status ow_run(ow_context *ctx, double delta, ow_cascade_params *params, int32
 /* Number of armed, unprocessed cascades (pass_num_cascades_remaining, wave_generator.gd:15). */
 int32_t ow_cascades_remaining(const ow_context *ctx);
 
-/* Blocks until everything enqueued by this context has finished. */
+/* Blocks until everything enqueued by this context has finished.  Also the point where a device-side failure shows: the
+ * frame kernels OR a bit into the context's status word when a bounded wait gives up (the wave-pair rendezvous of the
+ * 2048^2 kernels); a non-zero word turns this call -- and every other call that synchronises: ow_get_maps,
+ * ow_get_maps_f32, ow_readback_wait, ow_sample_surface -- into OW_ERR_HIP (reported once, then cleared).  The maps of
+ * the batches enqueued since the previous synchronisation are then invalid. */
 ow_status ow_sync(ow_context *ctx);
 
 /* ---- outputs: descriptors[&'displacement_map'/'normal_map'] (wave_generator.gd:34-35, water.gd:95-96) ---- */
@@ -226,6 +248,11 @@ int32_t ow_last_batch_cascades(const ow_context *ctx);
  * rocprofv3 kernel trace).  The extra pass-2 launches advance the foam recurrence: call it after a measurement,
  * never inside a simulation.  cascades_per_launch = how many cascades one launch of that batch covered. */
 ow_status ow_probe_kernel_times(ow_context *ctx, int32_t reps, float *pass1_ms, float *pass2_ms, int32_t *cascades_per_launch);
+
+/* Test hook: fault bits applied to the NEXT batch only.  bit 0: the second wave of every wave pair of the 2048^2 kernels
+ * never publishes its rendezvous epoch, so its partner's bounded wait gives up -- exercises the status-word path above.
+ * Never set in normal operation. */
+ow_status ow_debug_inject_fault(ow_context *ctx, uint32_t fault_bits);
 
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char *ow_last_error(void);

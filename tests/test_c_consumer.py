@@ -35,14 +35,10 @@ def test_builds_as_pedantic_c99_and_fails_loudly_without_a_device(tmp_path):
     assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
 
 
-@pytest.mark.gpu
-def test_c_program_and_python_mirror_agree(tmp_path):
+def mirror_schedule(n, frames):
+    """the schedule of examples/c_consumer.c / examples/wave_generator_host.cpp through the Python mirror:
+    (layers handed off, checksum, surface samples along the 64-point line)"""
     from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator
-    n, frames = 256, 12
-    r = subprocess.run([build(tmp_path), str(n), str(frames)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    out = dict(kv.split("=") for kv in r.stdout.split())
-    # the same schedule through the Python mirror
     tile, wind, dirs = [88.0, 57.0, 16.0], [10.0, 5.0, 20.0], [20.0, 15.0, 20.0]
     fetch, spread, whitecap, foam = [150.0, 150.0, 550.0], [0.2, 0.4, 0.4], [0.5, 0.5, 0.25], [8.0, 0.0, 3.0]
     params = [WaveCascadeParameters(tile_length=(tile[i], tile[i]), wind_speed=wind[i], wind_direction=dirs[i], fetch_length=fetch[i],
@@ -69,10 +65,23 @@ def test_c_program_and_python_mirror_agree(tmp_path):
         in_flight = layer
     total ^= take(in_flight)
     handed += 1
+    xz = np.stack([-40.0 + 1.25 * np.arange(64), 7.5 + 0.5 * np.arange(64)], axis=1).astype(np.float32)
+    return handed, total, gen.sample_surface(xz, [(1 / t, 1 / t, 1.0, 1.0) for t in tile])
+
+
+def check_against_mirror(stdout, n, frames):
+    out = dict(kv.split("=") for kv in stdout.split())
+    handed, total, s = mirror_schedule(n, frames)
     assert int(out["layers_handed_off"]) == handed == frames
     assert int(out["checksum"], 16) == total
-    xz = np.stack([-40.0 + 1.25 * np.arange(64), 7.5 + 0.5 * np.arange(64)], axis=1).astype(np.float32)
-    s = gen.sample_surface(xz, [(1 / t, 1 / t, 1.0, 1.0) for t in tile])
     lo, hi = out["wave_height"].strip("[]").split(",")
     assert abs(float(lo) - float(s["displacement"][:, 1].min())) < 1e-4 and abs(float(hi) - float(s["displacement"][:, 1].max())) < 1e-4
     assert int(out["spray_active"]) == int(s["spray_active"].sum())
+
+
+@pytest.mark.gpu
+def test_c_program_and_python_mirror_agree(tmp_path):
+    n, frames = 256, 12
+    r = subprocess.run([build(tmp_path), str(n), str(frames)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    check_against_mirror(r.stdout, n, frames)

@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: two `gloo` ranks shard 4 cascades 2 + 2 exactly as bench.py does on GPUs
-(godotoceanwaves_amd/sharding.py), each rank computes its own cascades (with the CPU oracle standing in for the
-device kernels -- this test is about the partitioning and the gather layout, not the arithmetic), all_gather,
-and rank 0 compares the gathered arrays with a single-process run of all 4 cascades."""
+"""The N > 1 path.  CPU: two `gloo` ranks shard the cascades exactly as bench.py does on GPUs (godotoceanwaves_amd/sharding.py),
+each rank computes its own cascades (with the CPU oracle standing in for the device kernels -- these tests are about the
+partitioning, the owned-layers-only message and the gather layout, not the arithmetic), all_gather or gather-to-root through
+MapGatherer, and rank 0 compares what arrived with a single-process run of all cascades.  GPU (-m gpu): the same object over
+the `nccl` backend (RCCL) at world = 1 with device-resident maps, a torch-owned stream and the generator's real kernels."""
 import os
 import socket
 import sys
@@ -27,7 +28,7 @@ def test_owned_cascades_partition():
         sharding.owned_cascades(2, 2, 1)
 
 
-def _worker(rank, world, port, n, per_rank, frames, out_dir):
+def _worker(rank, world, port, n, per_rank, frames, mode, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -39,35 +40,112 @@ def _worker(rank, world, port, n, per_rank, frames, out_dir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     ids = sharding.owned_cascades(rank, world, per_rank)
     g = H.oracle_generator(n, ids)
-    for _ in range(frames):
+    layers = max(2, per_rank)  # the array textures have max(2, C) layers (water.gd:91); only the owned ones may travel
+    disp = torch.full((layers, n, n, 4), 0x7E00, dtype=torch.int16)  # NaN bits in the spare layer: must never show up
+    norm = torch.full((layers, n, n, 4), 0x7E00, dtype=torch.int16)
+    gat = sharding.MapGatherer(torch, dist, world, rank, disp, norm, per_rank, mode=mode, root=0)
+    assert gat.bytes_sent == 2 * per_rank * n * n * 8
+    assert gat.bytes_received == (world * gat.bytes_sent if (mode == "all" or rank == 0) else 0)
+    for f in range(frames):
         g.update_all(UPDATE_DELTA)
-    disp = torch.from_numpy(np.stack([g.displacement(i) for i in range(per_rank)]).view(np.uint8))
-    norm = torch.from_numpy(np.stack([g.normal(i) for i in range(per_rank)]).view(np.uint8))
-    gathered = sharding.alloc_gather_buffers(torch, world, disp, norm)
-    sharding.gather_maps(dist, gathered, disp, norm)
+        for i in range(per_rank):
+            disp[i] = torch.from_numpy(g.displacement(i).view(np.int16))
+            norm[i] = torch.from_numpy(g.normal(i).view(np.int16))
+        gat.begin()      # a gather per tick; the last one is what is checked
+        gat.wait()
     dist.barrier()
     if rank == 0:
-        np.save(os.path.join(out_dir, "disp.npy"), gathered[0].numpy())
-        np.save(os.path.join(out_dir, "norm.npy"), gathered[1].numpy())
+        d, m = gat.maps()
+        np.save(os.path.join(out_dir, "disp.npy"), d.numpy())
+        np.save(os.path.join(out_dir, "norm.npy"), m.numpy())
+    elif mode == "root":
+        assert gat.maps() is None
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_shard_and_gather(tmp_path):
+@pytest.mark.parametrize("per_rank,mode", [(2, "all"), (1, "all"), (2, "root"), (1, "root")])
+def test_two_rank_gloo_shard_and_gather(tmp_path, per_rank, mode):
+    """per_rank = 1 is BASELINE config C4's shape (one cascade per GPU): the spare second array layer must not travel"""
     import torch.multiprocessing as mp
     import helpers as H
     from godotoceanwaves_amd.presets import UPDATE_DELTA
-    n, per_rank, world, frames = 128, 2, 2, 2
+    n, world, frames = 128, 2, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, n, per_rank, frames, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, per_rank, frames, mode, str(tmp_path)), nprocs=world, join=True)
     disp = np.load(tmp_path / "disp.npy").view(np.uint16)
     norm = np.load(tmp_path / "norm.npy").view(np.uint16)
-    assert disp.shape == (world, per_rank, n, n, 4)  # gathered as bytes, viewed back as RGBA16F bits
+    assert disp.shape == (world * per_rank, n, n, 4)  # entry g = global cascade g
     g = H.oracle_generator(n, list(range(world * per_rank)))
     for _ in range(frames):
         g.update_all(UPDATE_DELTA)
     for c in range(world * per_rank):
-        r, l = divmod(c, per_rank)
-        assert np.array_equal(disp[r, l], g.displacement(c)), c
-        assert np.array_equal(norm[r, l], g.normal(c)), c
+        assert np.array_equal(disp[c], g.displacement(c)), c
+        assert np.array_equal(norm[c], g.normal(c)), c
+
+
+def test_gatherer_argument_errors():
+    import torch
+    import torch.distributed as dist
+    from godotoceanwaves_amd import sharding
+    d = torch.zeros((2, 8, 8, 4), dtype=torch.float16)
+    with pytest.raises(ValueError):
+        sharding.MapGatherer(torch, dist, 1, 0, d, d, 1, mode="ring")
+    with pytest.raises(ValueError):
+        sharding.MapGatherer(torch, dist, 1, 0, d, d, 3)
+    g = sharding.MapGatherer(torch, dist, 1, 0, d, d + 1, 2)   # world = 1 without a process group: a plain copy
+    g.begin()
+    g.wait()
+    assert torch.equal(g.maps()[0], d) and torch.equal(g.maps()[1], d + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,overlap", [("all", True), ("root", True), ("all", False)])
+def test_rccl_gather_of_device_resident_maps_world_1(mode, overlap):
+    """bench.py's rank code at world = 1 over the `nccl` backend (= RCCL): the generator writes into torch-owned device
+    buffers (external_maps) on a torch-owned stream, MapGatherer snapshots them in stream order and gathers on its side
+    stream while later ticks overwrite the live maps -- what arrives equals ow_get_maps AT THE TIME OF THE SNAPSHOT."""
+    import torch
+    import torch.distributed as dist
+    from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, sharding
+    from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, C = 512, 1
+        layers = max(2, C)
+        compute = torch.cuda.Stream()
+        disp = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
+        norm = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
+        torch.cuda.synchronize()
+        gen = WaveGenerator()
+        gen.map_size = n
+        gen.stream = compute.cuda_stream
+        gen.external_maps = (disp.data_ptr(), norm.data_ptr())
+        gen.init_gpu(layers)
+        params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(0, 1, C)]
+        gat = sharding.MapGatherer(torch, dist, 1, 0, disp, norm, C, mode=mode, overlap=overlap, compute_stream=compute)
+        assert gat.bytes_sent == 2 * C * n * n * 8          # the spare array layer does not travel
+        gen.run(UPDATE_DELTA, params, 3)
+        gen.sync()
+        want = gen.get_maps(0)
+        gat.begin()
+        gen.run(UPDATE_DELTA, params, 5)                     # overwrites the live maps while the gather is in flight
+        gat.wait()
+        d, m = gat.maps()
+        assert d.shape == (C, n, n, 4)
+        assert np.array_equal(d[0].cpu().numpy().view(np.uint16), want[0].view(np.uint16))
+        assert np.array_equal(m[0].cpu().numpy().view(np.uint16), want[1].view(np.uint16))
+        gen.sync()
+        assert not np.array_equal(gen.get_maps(0)[0].view(np.uint16), want[0].view(np.uint16))
+        gat.begin()                                          # a second gather reuses the snapshot buffer safely
+        gat.wait()
+        now = gen.get_maps(0)
+        assert np.array_equal(gat.maps()[0][0].cpu().numpy().view(np.uint16), now[0].view(np.uint16))
+        gen.free()
+    finally:
+        dist.destroy_process_group()

@@ -25,12 +25,15 @@ float time_it(F f, int iters, hipStream_t s) {
 }
 
 int main(int argc, char **argv) {
-    constexpr int N = 1024;
+#ifndef KBENCH_N
+#define KBENCH_N 1024
+#endif
+    constexpr int N = KBENCH_N;
     const int C = argc > 1 ? atoi(argv[1]) : 4;
     const size_t pl = (size_t)N * N, L = C;
     DeviceBuffers buf{};
     CK(hipMalloc((void**)&buf.h0, L * pl * 8)); CK(hipMalloc(&buf.omega, L * pl * 4)); CK(hipMalloc((void**)&buf.T, L * pl * 32));
-    CK(hipMalloc(&buf.disp, L * pl * 8)); CK(hipMalloc(&buf.norm, L * pl * 8)); CK(hipMalloc(&buf.foam, L * pl * 2)); CK(hipMemset(buf.foam, 0, L * pl * 2));
+    CK(hipMalloc(&buf.disp, L * pl * 8)); CK(hipMalloc(&buf.norm, L * pl * 8)); CK(hipMalloc((void**)&buf.status, 64)); CK(hipMemset(buf.status, 0, 64)); CK(hipMalloc(&buf.foam, L * pl * 2)); CK(hipMemset(buf.foam, 0, L * pl * 2));
     const int dmode = argc > 3 ? atoi(argv[3]) : 0;  // 0 random O(1), 1 zeros, 2 spectrum-like (tiny away from the centre), 3 tiny but normal (1e-30)
     std::vector<float> hh(L * pl * 2); for (size_t i = 0; i < hh.size(); ++i) {
         float v = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.5f;
