@@ -574,7 +574,9 @@ template <int AUX = 0>
 OW_DEV void gstore16(GBuf b, uint32_t voff, uint32_t soff, f32x4 v) { __builtin_memcpy(b.p + voff + soff, &v, 16); }
 #endif
 // cache-policy bits of the buffer instructions (aux operand): 0 = default, 2 = nt (streamed once)
-constexpr int kAuxDefault = 0, kAuxNT = 2;
+// 16 = sc1: agent-scope coherence for THIS access (gfx942/950 memory model: an sc1 store writes through, an sc1 load never hits a
+// line that another XCD's store could have outdated) -- what data exchanged between blocks INSIDE one kernel must use
+constexpr int kAuxDefault = 0, kAuxNT = 2, kAuxAgent = 16;
 
 // Intermediate layout (device-private), one plane per packed layer:
 //   T[c][layer][y/16][x'][y%16] complex FP32 (8-byte units); one 128-byte line = 16 consecutive y of one x'.
@@ -929,6 +931,7 @@ struct Pass2 {
     OW_HD static constexpr uint32_t pcol_index(int y) { return (uint32_t)(y % T) * 16u + (uint32_t)(y / T); }
     // d[j] = i ky d[j] + sign * P[y_j]; slots j < 8 take the natural-order blocks o = 8..15 of P, slots j >= 8 blocks 0..7: two
     // halves, so that only eight of P's values are in registers at a time
+    template <int AUX = 0>
     static OW_DEV void derive_dx(cplx *d, int t, int xp, float dky, GBuf pcol_c) {
         const float s = (xp & 1) ? -1.0f : 1.0f;
 #pragma unroll
@@ -936,7 +939,7 @@ struct Pass2 {
             cplx p[P / 2];  // p[k] = P block o = 8 * (1 - half) + k
 #pragma unroll
             for (int i = 0; i < P / 4; ++i) {
-                const f32x4 v = gload16(pcol_c, (uint32_t)t * 128u, 16u * (uint32_t)(i + (P / 4) * (1 - half)));
+                const f32x4 v = gload16<AUX>(pcol_c, (uint32_t)t * 128u, 16u * (uint32_t)(i + (P / 4) * (1 - half)));
                 p[2 * i] = cplx{v.x, v.y};
                 p[2 * i + 1] = cplx{v.z, v.w};
             }

@@ -105,6 +105,15 @@ __device__ __forceinline__ void init_row_sync(int *flags, int pairs) {
     }
 }
 
+// Kernel arguments live in memory.  Left alone, the compiler loads each where it is first used and waits there, which at kernel
+// entry is a chain of two or three DEPENDENT ~0.6 us round trips before the first data load goes out (phase stamps of the
+// small-batch kernels: "loads issued" 1.3 us into k_pass1c_lp, 1.9 us into k_pass2c_lp).  Naming everything the kernel will need in
+// one place makes it one round trip: all scalar loads are issued together, one wait.
+__device__ __forceinline__ void fetch_arguments(const DeviceBuffers &b, const CascadeFrame &cf) {
+    asm volatile("" ::"s"(b.h0), "s"(b.omega), "s"(b.T), "s"(b.disp), "s"(b.norm), "s"(b.foam), "s"(b.tw), "s"(b.pcol), "s"(b.rrow), "s"(b.status));
+    asm volatile("" ::"s"(cf.tile_x), "s"(cf.tile_y), "s"(cf.time), "s"(cf.whitecap), "s"(cf.foam_grow_rate), "s"(cf.foam_decay), "s"(cf.cascade));
+}
+
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -272,6 +281,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1(Devic
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
     int slot, row0;
     p2_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int xp = row0 + rw;
     const uint32_t tex = (uint32_t)(xp * N + t);
     const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
@@ -597,6 +609,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     int slot, row0;
     p2_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int xp = row0 + rw;
     const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
     const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
@@ -692,6 +705,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
     int slot, row0;
     p1_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
@@ -746,6 +760,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
     constexpr int BPC = N / ROWS;
     const int slot = blockIdx.x / BPC, row0 = (blockIdx.x % BPC) * ROWS;
     const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
     const int xp = row0 + r;
     const uint32_t tex = (uint32_t)(xp * N + t);
     const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));  // scratch: indexed by launch slot, reused by every batch
@@ -793,61 +808,48 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffer
 
 // ===================================================================================================
 // LAYER-PARALLEL + COMPACT INTERMEDIATE (N >= 256): the small-batch kernels on the two-and-a-half-layer intermediate.
-// Pass 1: grid (rows/8, 6); y = 0..2 the compact layers (lower-half blocks of layer 1 leave at once), y = 3..5 the three extra
-// transforms of texel row 0 (only the block that owns row 0 stays).  Pass 2: the four lane groups of a row compute F0..F3.
+// Pass 1: one ITEM = (8 rows, L): L = 0..2 the compact layers (layer 1 exists for the upper half of the rows only), L = 3..5 the
+// three extra transforms of texel row 0 (rows 0..7 of a cascade only).  Pass 2: one item = plan_lp_rows(N) rows; the four lane
+// groups of a row compute F0..F3.  The item bodies are functions of (item, lane) so that they can be driven by other launch shapes
+// (the stand-alone kernels below: one item per block; tools/tick_loop_experiment.h: a persistent loop over items and ticks).
 // ===================================================================================================
-template <int N, int AUX_T = kAuxDefault, bool STAMPS = false>
-__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
-    WaveStamps<STAMPS> ws;
-    ws.at(0, 0.0f);
+struct NoStamps {
+    __device__ __forceinline__ void at(int, float) {}
+};
+// issued(a15, om15): called right after the item's global loads have been issued (the stand-alone kernel commits its
+// twiddle prefetch there); tslot = slot of the scratch intermediate / side buffers this item writes
+template <int N, int AUX_T, class Issued, class WS>
+__device__ __forceinline__ void pass1c_lp_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int L, int tau,
+                                               cplx *tw_lds, cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws) {
     constexpr int Tn = plan_T(N), P = kP;
-    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
-    int slot, row0;
-    p1_block_to_rows<N>(slot, row0);
-    const int L = blockIdx.y;                 // 0..2: layer, 3..5: row-0 transform Q = L - 2
-    if (L == 1 && row0 < N / 2) return;       // hz of the lower rows is the conjugate of the mirrored rows': not transformed
-    if (L >= 3 && row0 != 0) return;
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
-    const int tau = threadIdx.x;
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
-    RowSync<N> rs;
-    rs.attach(sync_flags, rw, (tau / 64) & 1);
-    rs.watch(buf.status, args.c[0].fault);
-    init_row_sync<N>(sync_flags, kWgRows);
-    const CascadeFrame cf = args.c[slot];
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
-    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
-    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
     cplx h[P];
     {
-        TwPrefetch<N> twp;
-        tw_fetch<N>(twp, buf.tw);
         cplx a[P], b[P];
         float om[P];
         Pass1<N>::load_raw(a, b, om, t, y, h0_c, om_c);
         ws.at(1, 0.0f);                 // loads issued
-        tw_commit<N>(twp, tw_lds);
-        ws.at(2, tw_lds[0].x);          // table in LDS, block barrier passed
+        issued();
         ws.at(3, a[15].x + om[15]);     // the wave's own data has arrived
-        Pass1<N>::modulate(h, a, b, om, cf.time);
+        Pass1<N>::modulate(h, a, b, om, time);
     }
     ws.at(4, h[15].x);                  // modulated
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
     Pass1<N>::wave_numbers(ik, t, ky, dkx);
-    if (L == 0 && t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
+    if (L == 0 && t == 0) gstore8<AUX_T>(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
     cplx d[P];
     OW_SCHED_FENCE();
-    switch (L) {  // block-uniform
+    switch (L) {  // item-uniform
         case 0: Pass1<N>::template layer_input_c<0>(d, h, ik, t, ky, dkx); break;
         case 1: Pass1<N>::template layer_input_c<1>(d, h, ik, t, ky, dkx); break;
         case 2: Pass1<N>::template layer_input_c<2>(d, h, ik, t, ky, dkx); break;
@@ -859,73 +861,85 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
     ws.at(5, d[15].x);                  // layer input built
     row_ifft<N>(d, t, lds_row, tw_lds, rs);
     ws.at(6, d[15].x);                  // transformed
-    if (L >= 3) {  // straight to the side buffer, lanes of row 0 only (the other rows of the block computed nothing of use)
+    if (L >= 3) {  // straight to the side buffer, lanes of row 0 only (the other rows of the item computed nothing of use)
         if (y == 0) {
 #pragma unroll
-            for (int o = 0; o < P; ++o) gstore8(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)(L - 2) * 8u, d[OutMap<N>::slot_of(o)]);
+            for (int o = 0; o < P; ++o) gstore8<AUX_T>(rrow_c, (uint32_t)(t + Tn * o) * 32u, (uint32_t)(L - 2) * 8u, d[OutMap<N>::slot_of(o)]);
         }
-        ws.write(stamps, (plan_wg_threads(N) + 63) / 64, (unsigned long long)L);
         return;
     }
     rs.sync();
     Pass1<N>::stage_write(d, t, lds_row);
-    lds_barrier();
+    lds_barrier();                      // (block-wide: every item of a block takes this path or none does)
     ws.at(7, 0.0f);                     // staged, block barrier passed
     Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
     ws.at(8, 0.0f);                     // stores issued
-    ws.write(stamps, (plan_wg_threads(N) + 63) / 64, (unsigned long long)L);   // [14] = stores acknowledged
 }
 
-template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault, bool STAMPS = false>
-__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+template <int N, int AUX_T = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
     WaveStamps<STAMPS> ws;
     ws.at(0, 0.0f);
-    constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
-    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + plan_sync_flag_cplx(N, plan_lp_rows(N) * kLayers)];
+    static_assert(plan_T(N) >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const int L = blockIdx.y;                 // 0..2: layer, 3..5: row-0 transform Q = L - 2
+    if (L == 1 && row0 < N / 2) return;       // hz of the lower rows is the conjugate of the mirrored rows': not transformed
+    if (L >= 3 && row0 != 0) return;
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     const int tau = threadIdx.x;
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
+    init_row_sync<N>(sync_flags, kWgRows);
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    pass1c_lp_item<N, AUX_T>(buf, cf, cf.time, slot, row0, L, tau, tw_lds, rows_lds, rs, [&] {
+        tw_commit<N>(twp, tw_lds);
+        ws.at(2, tw_lds[0].x);          // table in LDS, block barrier passed
+    }, ws);
+    ws.write(stamps, (plan_wg_threads(N) + 63) / 64, (unsigned long long)L);   // [14] = stores acknowledged
+}
+
+// tau = thread index inside the item's plan_lp_threads(N) lanes; rows_lds = the item's plan_lp_rows(N) x 4 row regions
+template <int N, bool F32, int AUX_T, int AUX_O, class Issued, class WS>
+__device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds,
+                                               cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws) {
+    constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
     const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);  // which of F0..F3 this lane group transforms (wave-uniform)
     const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
-    constexpr int BPC = N / ROWS;
-    const int slot = blockIdx.x / BPC, row0 = (blockIdx.x % BPC) * ROWS;
-    const CascadeFrame cf = args.c[slot];
     const int xp = row0 + r;
     const uint32_t tex = (uint32_t)(xp * N + t);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
-    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
-    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
     const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
     const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
     const float dky = (2.0f * kPi) / cf.tile_y;
     auto region = [&](int row, int layer) { return rows_lds + (layer * ROWS + row) * plan_region_cplx(N); };
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
-    RowSync<N> rs;
-    rs.attach(sync_flags, g * ROWS + r, (tau / 64) & 1);
-    rs.watch(buf.status, args.c[0].fault);
-    init_row_sync<N>(sync_flags, ROWS * kLayers);
 
-    TwPrefetch<N> twp;
-    tw_fetch<N>(twp, buf.tw);
     cplx d[P];
     switch (g) {  // group-uniform
         case 0: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 0, T_c); break;
         case 1:
             Pass2<N>::template load_layer<AUX_T>(d, t, xp, 0, T_c);
-            Pass2<N>::derive_dx(d, t, xp, dky, pcol_c);
+            Pass2<N>::template derive_dx<AUX_T>(d, t, xp, dky, pcol_c);
             break;
         case 2: Pass2<N>::template load_c1<AUX_T>(d, t, xp, dky, T_c); break;
         default: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 2, T_c); break;
     }
-    if (g != 0) Pass2<N>::put_row0(d, t, gload8(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
+    if (g != 0) Pass2<N>::put_row0(d, t, gload8<AUX_T>(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
     const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
     ws.at(1, 0.0f);                     // loads issued
-    tw_commit<N>(twp, tw_lds);
-    ws.at(2, tw_lds[0].x);              // table in LDS, block barrier passed
+    issued();
     ws.at(3, d[15].x + foam_bits.x);    // the wave's own data has arrived
     row_ifft<N>(d, t, region(r, g), tw_lds, rs);
     ws.at(6, d[15].x);                  // transformed
@@ -954,8 +968,34 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
     gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
     ws.at(8, 0.0f);                     // unpacked, stores issued
-    ws.write(stamps, (plan_lp_threads(N) + 63) / 64, (unsigned long long)g);   // [14] = stores acknowledged
 }
 
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+    WaveStamps<STAMPS> ws;
+    ws.at(0, 0.0f);
+    constexpr int Tn = plan_T(N), ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + plan_sync_flag_cplx(N, plan_lp_rows(N) * kLayers)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    constexpr int BPC = N / ROWS;
+    const int slot = blockIdx.x / BPC, row0 = (blockIdx.x % BPC) * ROWS;
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_lp_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, (tau / PER_LAYER) * ROWS + (tau % PER_LAYER) / Tn, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
+    init_row_sync<N>(sync_flags, ROWS * kLayers);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    pass2c_lp_item<N, F32, AUX_T, AUX_O>(buf, cf, slot, row0, tau, tw_lds, rows_lds, rs, [&] {
+        tw_commit<N>(twp, tw_lds);
+        ws.at(2, tw_lds[0].x);          // table in LDS, block barrier passed
+    }, ws);
+    ws.write(stamps, (plan_lp_threads(N) + 63) / 64, (unsigned long long)(tau / PER_LAYER));   // [14] = stores acknowledged
+}
 
 }  // namespace ow

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 F="--offload-arch=gfx950 -O3 -std=c++17 -I godotoceanwaves_amd/csrc"
 hipcc $F tools/kbench.hip -o tools/kbench &
 hipcc $F -DKBENCH_N=2048 tools/kbench.hip -o tools/kbench_2048 &
-hipcc $F -DKS_N=256 tools/kbench_small.hip -o tools/kbench_small_256 &
-hipcc $F -DKS_N=512 tools/kbench_small.hip -o tools/kbench_small_512 &
+hipcc $F -I tools -DKS_N=256 tools/kbench_small.hip -o tools/kbench_small_256 &
+hipcc $F -I tools -DKS_N=512 tools/kbench_small.hip -o tools/kbench_small_512 &
 wait
 ls -la tools/kbench tools/kbench_2048 tools/kbench_small_256 tools/kbench_small_512
