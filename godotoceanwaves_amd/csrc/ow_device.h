@@ -359,6 +359,27 @@ struct OutMap {
 };
 
 // ------------------------------------------------------------------------------------
+// SPLIT PLAN for pass 1 of rows that do not fit one wave at 16 points per lane (N = 2048): decimation in time,
+//   X[k] = E[k] + W_N^k O[k],   X[k + N/2] = E[k] - W_N^k O[k],   E / O = transforms of the even / odd elements (length N/2),
+// one WAVE per parity.  Each wave runs the N/2 plan (one LDS exchange inside the wave, the last exchange on the row-swap
+// instructions): no rendezvous with the partner wave during the transform.  The final radix-2 step needs both waves' results,
+// and pass 1 stages its results in LDS for the transposed store anyway: both waves stage their half and the STORING threads
+// combine E and O on their way out, so the two waves of a row never have to meet.
+// Physical lane (parity w, lane tp) plays the LOGICAL lane t = 2 tp + w of the N plan: its texels are t + (N/16) rot(j), i.e.
+// all input-side lane code (loads, modulation, wave numbers, layer inputs, the Nyquist-line special cases) is the N plan's,
+// called with the logical lane.  The (-1)^x' half of the ifftshift is a shift by N/2 of the full sequence = N/4 of each parity
+// subsequence = 8 lane-strides of the N/2 plan: the same slot rotation.
+// (Pass 2 keeps the N plan: measured, the same split there -- half exchange between partner lanes, two rendezvous per transform
+// instead of four -- is no faster: 33.7 against 32.3 us at 2048^2 x 1, 34.9 against 35.2 at x 4.)
+// ------------------------------------------------------------------------------------
+constexpr bool plan_split(int N) { return N == 2048; }
+// exp(+2 pi i m / 32) for compile-time m in [0, 16] (the ordinal part of W_N^k; the lane part comes from a table)
+constexpr float kRootCos32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                                 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
+constexpr float root32_cos(int i) { return i <= 8 ? kRootCos32[i] : -kRootCos32[16 - i]; }
+constexpr float root32_sin(int i) { return i <= 8 ? kRootCos32[8 - i] : kRootCos32[i - 8]; }
+
+// ------------------------------------------------------------------------------------
 // Accurate sin/cos of an FP32 phase up to ~2.5e4 rad (never the hardware approximations: SURVEY.md H1).
 // Three-step Cody-Waite reduction by pi in FP32 with FMA (pi = P1 + P2 + P3, P1 8 bits and P2 11 bits so that
 // n*P1 and n*P2 are exact for n < 2^13 and the first two subtractions cancel exactly), then minimax polynomials

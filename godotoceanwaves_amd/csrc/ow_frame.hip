@@ -49,6 +49,12 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
             return hipGetLastError();
         }
     }
+    if constexpr (plan_split(N)) {
+        if (fam == 3) {  // a row spans two waves: the split plan (one wave per parity, no rendezvous in pass 1)
+            launch(k_pass1c_split<N>, dim3(blocks * (kWgRows / OW_SPLIT_P1_ROWS)), dim3(SplitGeo<N, OW_SPLIT_P1_ROWS>::kThreads), s, lt, buf, args);
+            return hipGetLastError();
+        }
+    }
     if constexpr (plan_T(N) >= 16) {
         if (fam == 3) {
             launch(k_pass1c<N>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, (Stamp *)nullptr);

@@ -217,10 +217,11 @@ __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cp
 //    16g+8..16g+15) are neighbours on one XCD, so the halves meet in one L2 before they are written back;
 //  * the 16-row group g and its mirror group N/16-1-g (rows N-y) are on the same XCD next to each other: both
 //    read the same h0 / omega lines (Pass1::load_modulate) and the XCD's L2 fetches them from HBM once.
-template <int N>
+// SUB > 1: the 8-row unit is shared by SUB consecutive blocks of 8 / SUB rows each (split plan with smaller blocks)
+template <int N, int SUB = 1>
 __device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
     constexpr int G = N / 16;  // 16-row groups per cascade; 2*G blocks per cascade
-    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    const int b = blockIdx.x / SUB, x = b & 7, i = b >> 3;
     if constexpr (G >= 16) {
         constexpr int PER = G / 4;  // blocks per XCD per cascade: G/16 mirror pairs x 2 groups x 2 halves
         slot = i / PER;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
         slot = grow / N;
         row0 = grow % N;
     }
+    if constexpr (SUB > 1) row0 += (int)(blockIdx.x % SUB) * (kWgRows / SUB);
 }
 template <int N>
 __device__ __forceinline__ void p2_block_to_rows(int &slot, int &row0) {
@@ -674,6 +676,207 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
         const int tr = opaque(t);
         Pass2<N>::template after_f3<F32, AUX_O>(f3, dhx_dx, c2, gx_pk, foam_pk, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
         Pass2<N>::store_foam(foam_pk, tr, xp, foam_c);
+    }
+}
+
+// ===================================================================================================
+// SPLIT-PLAN compact pass 1 for N = 2048 (see "SPLIT PLAN" in ow_device.h): a row is two waves, one per parity of the element
+// index, each running the N/2 plan on its own; the radix-2 step that joins them is done by the storing threads, so the layer
+// transforms need no rendezvous between the waves of a row.  Block = 8 rows = 16 waves; wave 2r + w = parity w of row r.
+// Twiddles: buf.tw_split = [table of the N/2 plan][W_N^k, k = 0 .. N/2 - 1].
+// (Measured on the same box: 33.5 us per 2048^2 cascade against 36.0 for k_pass1c<2048>, whose rows exchange across their two
+// waves four times per transform; x 4: 39.4 against 42.2.)
+// ===================================================================================================
+#ifndef OW_SPLIT_P1_ROWS
+#define OW_SPLIT_P1_ROWS 8
+#endif
+template <int N, int ROWS = kWgRows>
+struct SplitGeo {
+    static constexpr int H = N / 2, TH = plan_T(H), R = plan_region_cplx(H), TW = plan_tw_total(H);
+    static constexpr int kRows = ROWS;                       // rows per block
+    static constexpr int kThreads = 2 * ROWS * TH;           // 1024 for 8 rows
+    static constexpr int kLdsCplx = TW + 2 * ROWS * R;       // table + virtual-row regions (E regions of the rows, then O regions)
+    static constexpr int kTwPerThread = (TW + kThreads - 1) / kThreads;
+};
+// the N/2-plan table into LDS: one entry per thread, asked for before the kernel's first data loads, committed after them
+template <class SG>
+struct SplitTw {
+    cplx v[SG::kTwPerThread];
+};
+template <class SG>
+__device__ __forceinline__ void split_tw_fetch(SplitTw<SG> &p, const cplx *__restrict__ tw_split) {
+#pragma unroll
+    for (int k = 0; k < SG::kTwPerThread; ++k) {
+        const int i = (int)threadIdx.x + k * SG::kThreads;
+        p.v[k] = tw_split[i < SG::TW ? i : 0];
+    }
+}
+template <class SG>
+__device__ __forceinline__ void split_tw_commit(const SplitTw<SG> &p, cplx *tw_lds) {
+#pragma unroll
+    for (int k = 0; k < SG::kTwPerThread; ++k) {
+        const int i = (int)threadIdx.x + k * SG::kThreads;
+        if (i < SG::TW) tw_lds[i] = p.v[k];
+    }
+    lds_barrier();
+}
+
+template <int N, int ROWS = OW_SPLIT_P1_ROWS, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
+__global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_split(DeviceBuffers buf, FrameArgs args) {
+    using SG = SplitGeo<N, ROWS>;
+    constexpr int H = SG::H, TH = SG::TH, P = kP, LC = Pass1<N>::kCompactLayers, T = plan_T(N);
+    __shared__ __attribute__((aligned(16))) cplx lds[SG::kLdsCplx + plan_sync_flag_cplx(N, ROWS)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + SG::TW;
+    const int tau = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tau / 64), rw = wv >> 1, w = wv & 1;  // row inside the block, parity
+    const int tp = tau % 64, t = 2 * tp + w;                                              // physical lane, logical lane of the N plan
+    cplx *vrow = rows_lds + (w * ROWS + rw) * SG::R;
+    const uint32_t plane = (uint32_t)N * N;
+    RowSync<H> rs;    // inside one wave: compiler ordering only
+    RowSync<N> pair;  // the two waves of a row (used by the pair that owns texel row 0 only)
+    int *sync_flags = reinterpret_cast<int *>(lds + SG::kLdsCplx);
+    pair.attach(sync_flags, rw, w);
+    pair.watch(buf.status, args.c[0].fault);
+    if ((int)threadIdx.x < 2 * ROWS) sync_flags[threadIdx.x] = 0;  // made visible by the block barrier of the twiddle commit
+
+    int slot, row0;
+    p1_block_to_rows<N, kWgRows / ROWS>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    const int y = row0 + rw;
+    const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
+    const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+
+    // storing thread: row q of the block, x' = xi + T m (and + N/2): W_N^xi from the table, the ordinal part is compile time
+    const int q = tau % ROWS, xi = tau / ROWS;  // xi in [0, T)
+    cplx h[P];
+    cplx wxi;
+    {
+        SplitTw<SG> twv;
+        split_tw_fetch<SG>(twv, buf.tw_split);
+        wxi = buf.tw_split[SG::TW + xi];
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
+        split_tw_commit<SG>(twv, tw_lds);
+        Pass1<N>::modulate(h, a, b, om, cf.time);
+    }
+    const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
+    const float ky = (float)(y - N / 2) * dky;
+    float ik[P];
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
+
+    // E[k] +- W_N^k O[k] for k = xi + T m, m = 2g and 2g + 1 (chunk g of four): staged values of row q
+    const cplx *e_reg = rows_lds + q * SG::R, *o_reg = rows_lds + (ROWS + q) * SG::R;
+    auto combine = [&](int m, cplx &lo, cplx &hi) {
+        const cplx e = lds_read(e_reg + xi + T * m), o = lds_read(o_reg + xi + T * m);
+        // W_N^(xi + T m) = W_N^xi * exp(2 pi i m / 16): two packed instructions where it is used.  (The base is made opaque so that
+        // the eight products are NOT kept in registers from one layer to the next: 14 VGPRs this kernel does not have.)
+        cplx wx = wxi;
+        opaque_inplace(wx);
+        cplx tw = wx;
+        switch (m) {
+            case 1: tw = cmul_const(wx, root32_cos(2), root32_sin(2)); break;
+            case 2: tw = cmul_const(wx, root32_cos(4), root32_sin(4)); break;
+            case 3: tw = cmul_const(wx, root32_cos(6), root32_sin(6)); break;
+            case 4: tw = cmuli(wx); break;
+            case 5: tw = cmul_const(wx, root32_cos(10), root32_sin(10)); break;
+            case 6: tw = cmul_const(wx, root32_cos(12), root32_sin(12)); break;
+            case 7: tw = cmul_const(wx, root32_cos(14), root32_sin(14)); break;
+            default: break;
+        }
+        const cplx z = cmul(o, tw);
+        lo = cadd(e, z);
+        hi = csub(e, z);
+    };
+    const uint32_t voff = t_unit(N, 0, xi, row0 + q) * 8u;
+    auto store_chunk = [&](int layer, int g) {  // x' = xi + T m and xi + T (m + 8), m = 2g, 2g + 1
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int m = 2 * g + mm;
+            cplx lo, hi;
+            combine(m, lo, hi);
+            gstore8<AUX_T>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * m, 0)) * 8u, lo);
+            gstore8<AUX_T>(T_c, voff, (t_unit(N, layer, 0, 0) + t_unit(N, 0, T * (m + 8), 0)) * 8u, hi);
+            OW_SCHED_FENCE();
+        }
+    };
+
+    // The two waves that hold texel row 0 do the three extra transforms of that row between themselves, straight to the side
+    // buffer: they stage E / O in their own regions, meet (the only rendezvous of this kernel: one pair per cascade), and each
+    // lane joins and stores the sixteen x' = (tp + TH w) + T m, m = 0..15.  No block barrier is involved, so the other fourteen
+    // waves of the block are not held up (measured: done by the whole block around block barriers, this tail cost 8 us per launch).
+    if (__builtin_amdgcn_readfirstlane(y) == 0) {
+        const int xr = tp + TH * w;  // this lane's x' (mod T) in the join
+        const cplx wxr = buf.tw_split[SG::TW + xr];
+        const cplx *e0 = rows_lds + rw * SG::R, *o0 = rows_lds + (ROWS + rw) * SG::R;
+#pragma unroll
+        for (int Q = 1; Q <= 3; ++Q) {
+            cplx d[P];
+            OW_SCHED_FENCE();
+            {
+                const float kyo = opaque(ky), dkxo = opaque(dkx);
+                const int to = opaque(t);
+#pragma unroll
+                for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
+                if (Q == 1) Pass1<N>::template row0_input<1>(d, h, ik, to, kyo, dkxo);
+                if (Q == 2) Pass1<N>::template row0_input<2>(d, h, ik, to, kyo, dkxo);
+                if (Q == 3) Pass1<N>::template row0_input<3>(d, h, ik, to, kyo, dkxo);
+            }
+            OW_SCHED_FENCE();
+            row_ifft<H, false>(d, tp, vrow, tw_lds, rs);
+            rs.sync();
+#pragma unroll
+            for (int o = 0; o < P; ++o) vrow[tp + TH * o] = d[OutMap<H>::slot_of(o)];
+            pair.sync();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const cplx e = lds_read(e0 + xr + T * m), o = lds_read(o0 + xr + T * m);
+                cplx wx = wxr;  // (opaque: the eight products are formed where they are used, not kept across the three transforms)
+                opaque_inplace(wx);
+                const cplx z = cmul(o, cmul_const(wx, root32_cos(2 * m), root32_sin(2 * m)));
+                gstore8(rrow_c, (uint32_t)(xr + T * m) * 32u, (uint32_t)Q * 8u, cadd(e, z));
+                gstore8(rrow_c, (uint32_t)(xr + T * (m + 8)) * 32u, (uint32_t)Q * 8u, csub(e, z));
+                OW_SCHED_FENCE();
+            }
+            pair.sync();  // both waves have read the regions: free for the next transform
+        }
+    }
+
+    const bool lower = row0 < N / 2;  // rows below N/2 skip layer 1 (block-uniform)
+#pragma unroll
+    for (int L = 0; L < LC; ++L) {
+        if (L == 1 && lower) continue;
+        cplx d[P];
+        OW_SCHED_FENCE();
+        {
+            const float kyo = opaque(ky), dkxo = opaque(dkx);
+            const int to = opaque(t);
+#pragma unroll
+            for (int j = 0; j < P; ++j) opaque_inplace(h[j]);
+            auto drain = [&](int g) {  // the previous layer that was staged: L - 1, or 0 when layer 1 was skipped
+                if (L > 0) store_chunk((L == 2 && lower) ? 0 : L - 1, g);
+            };
+            if (L == 0) Pass1<N>::template layer_input_c<0>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 1) Pass1<N>::template layer_input_c<1>(d, h, ik, to, kyo, dkxo, drain);
+            if (L == 2) Pass1<N>::template layer_input_c<2>(d, h, ik, to, kyo, dkxo, drain);
+        }
+        OW_SCHED_FENCE();
+        if (L > 0) row_ifft<H, true>(d, tp, vrow, tw_lds, rs);  // (block gate: the staged rows have been drained by every wave)
+        else row_ifft<H, false>(d, tp, vrow, tw_lds, rs);
+        rs.sync();
+#pragma unroll
+        for (int o = 0; o < P; ++o) vrow[tp + TH * o] = d[OutMap<H>::slot_of(o)];
+        lds_barrier();
+        if (L == LC - 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) store_chunk(L, g);
+        }
     }
 }
 

@@ -20,6 +20,7 @@ struct DeviceBuffers {
     // compact-intermediate side buffers (Pass1::layer_input_c), scratch of one batch like T:
     cplx *pcol;     // [launch slot][N]     P(ky) of texel column id.x = 0, in pass-2 lane order (Pass2::pcol_index)
     cplx *rrow;     // [launch slot][N x'][4] row transforms Q1..Q3 of texel row id.y = 0 (entry 0 unused)
+    const cplx *tw_split; // split plan (N = 2048): [twiddle table of the N/2 plan][W_N^k, k = 0 .. N/2 - 1]; nullptr otherwise
     uint32_t *status; // device status word (page-locked host memory, mapped): kernels OR kStatus* bits into it
 };
 

@@ -54,7 +54,7 @@ struct ow_context {
     hipStream_t stream = nullptr;
     bool own_stream = false, own_disp = false, own_norm = false;
     ow::DeviceBuffers buf{};
-    ow::cplx *tw_dev = nullptr;
+    ow::cplx *tw_dev = nullptr, *tw_split_dev = nullptr;
     // generator state per invocation of update() (wave_generator.gd:13-15).  The reference keeps a reference to the caller's
     // Array; a C caller's memory is only borrowed for the duration of a call, so the context keeps COPIES of the armed records
     // (ow_set_cascade_params / ow_get_cascade_params are the explicit form of "the parameter objects are live")
@@ -94,6 +94,8 @@ size_t plane(const ow_context *c) { return (size_t)c->n * c->n; }
 // (x 5: 82 us against 84.5 as 4 + 1; x 6: 88.5 against 96); beyond that the intermediate and the inputs of a pair no
 // longer fit the 256 MiB Infinity Cache together (x 8 in one pair: 126-137 us, erratic) and the tick is split into equal
 // batches of at most 4 Mi texels (x 7: 4 + 3, x 8: 4 + 4 = 121-125 us; 2048^2: one cascade per pair).
+// (2048^2 with 8 or 16 Mi texels per pair, measured in round 2: x 4 310.7 -> 308.1 / 300.9 us per tick, while 1024^2 x 8 gets worse,
+// 125.4 -> 136.8: left at 4 Mi.)
 constexpr size_t kSinglePairTexels = 6u << 20, kBatchTexels = 4u << 20;
 int max_batch(const ow_context *c) {  // the most cascades a pair ever takes: sizes the scratch buffers
     const size_t pl = (size_t)c->n * c->n;
@@ -350,8 +352,13 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     std::vector<ow::cplx> tw;
     ow::make_twiddles(c->n, tw);
     OW_ALLOC(c->tw_dev, tw.size() * sizeof(ow::cplx));
+    std::vector<ow::cplx> tw_split;
+    if (ow::make_split_twiddles(c->n, tw_split)) { OW_ALLOC(c->tw_split_dev, tw_split.size() * sizeof(ow::cplx)); }
 #undef OW_ALLOC
     c->buf.tw = c->tw_dev;
+    c->buf.tw_split = c->tw_split_dev;
+    if (c->tw_split_dev && hipMemcpyAsync(c->tw_split_dev, tw_split.data(), tw_split.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return bail(fail(OW_ERR_HIP, "twiddle upload failed"));
     // Vulkan images start undefined; foam must start from a defined state: zero
     if (hipMemcpyAsync(c->tw_dev, tw.data(), tw.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
@@ -382,6 +389,7 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->buf.pcol);
     (void)hipFree(c->buf.rrow);
     (void)hipFree(c->tw_dev);
+    (void)hipFree(c->tw_split_dev);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipFree(c->snap_dev);

@@ -23,6 +23,25 @@ inline void fill_twiddles(std::vector<cplx> &tw) {
     }
 }
 
+// split plan (N = 2048): [table of the N/2 plan][W_N^k = exp(+2 pi i k / N), k = 0 .. N/2 - 1], FP64 rounded once to FP32
+template <int N>
+inline void fill_split_twiddles(std::vector<cplx> &tw) {
+    fill_twiddles<N / 2>(tw);
+    tw.resize(plan_tw_total(N / 2));
+    for (int k = 0; k < N / 2; ++k) {
+        const double a = 2.0 * 3.14159265358979323846 * (double)k / (double)N;
+        tw.push_back(cplx{(float)std::cos(a), (float)std::sin(a)});
+    }
+}
+inline bool make_split_twiddles(int n, std::vector<cplx> &tw) {
+    if (n == 2048) {
+        fill_split_twiddles<2048>(tw);
+        return true;
+    }
+    tw.clear();
+    return false;
+}
+
 inline bool make_twiddles(int n, std::vector<cplx> &tw) {
     switch (n) {
         case 128: fill_twiddles<128>(tw); return true;
