@@ -225,6 +225,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     k1, k2 = FAMILY_BYTES[family]
     first = p1_ms >= p2_ms
     dom = ("k_pass1" if first else "k_pass2") + SUFFIX[family]  # the name rocprofv3 lists the kernel under
+    if first and n == 2048 and family == "compact":
+        dom = "k_pass1c_split"  # rows that span two waves: the split-plan pass 1
     dom_ms = max(p1_ms, p2_ms)
     dom_bpt, dom_contract = (k1, CONTRACT_BYTES[0]) if first else (k2, CONTRACT_BYTES[1])
     gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -307,6 +307,37 @@ def test_compact_kernels_on_parameter_range_edges(names):
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (names[i], cname, H.relmax(f32[..., c], ref[..., c]))
 
 
+@pytest.mark.parametrize("names", [("non_square_tile", "late_time"), ("wrapping_seed", "whitecap_foam_extremes")])
+def test_split_plan_pass1_on_parameter_range_edges(names):
+    """2048^2 (beyond the reference's sizes, BASELINE config C5): pass 1 is the split plan there (k_pass1c_split: one wave per parity
+    of the element index, the radix-2 join done by the storing threads, texel row 0 by its own wave pair).  Non-square tiles, t = 0
+    with a wrapping seed, the largest phases and the smallest tile, two cascades = two batches."""
+    from edge_presets import edge_presets
+    n, presets = 2048, [edge_presets()[k] for k in names]
+    gen = WaveGenerator()
+    gen.map_size, gen.debug_f32 = n, True
+    gen.init_gpu(2)
+    params = [WaveCascadeParameters(**p) for p in presets]
+    og = O.Generator(n, 2, DEPTH)
+    for i, p in enumerate(presets):
+        H.set_params(og.params[i], p)
+    for _ in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == "compact" and gen.last_batch_cascades() == 1
+    for i in range(2):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        assert np.isfinite(f32).all()
+        for c, cname in enumerate(H.CHANNELS):
+            if cname == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, cname)
+            elif np.abs(ref[..., c]).max() > 0:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, cname)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
+
+
 @pytest.mark.parametrize("n,ids,family", [(1024, [0, 1, 2], "compact"), (512, [0, 1, 2, 3, 4, 5, 6, 7], "compact"),
                                           (256, [0, 1, 2, 3, 4, 5, 6, 7], "layer_parallel_compact"), (128, [0, 1, 2, 3, 4, 5, 6, 7], "layer_parallel"),
                                           (2048, [1], "compact")])
