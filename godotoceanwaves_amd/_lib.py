@@ -11,6 +11,7 @@ OW_FLAG_DEBUG_F32 = 1
 OW_FLAG_KERNELS_STANDARD = 2
 OW_FLAG_KERNELS_LAYER_PARALLEL = 4
 OW_FLAG_KERNELS_COMPACT = 8
+OW_FLAG_NO_TICK_GROUPS = 16
 OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "ow_cascades_remaining": (C.c_int32, [C.c_void_p]),
     "ow_last_kernel_family": (C.c_int32, [C.c_void_p]),
     "ow_last_batch_cascades": (C.c_int32, [C.c_void_p]),
+    "ow_tick_group_depth": (C.c_int32, [C.c_void_p]),
     "ow_sync": (C.c_int, [C.c_void_p]),
     "ow_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
     "ow_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

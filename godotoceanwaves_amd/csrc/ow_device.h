@@ -523,6 +523,14 @@ struct CascadeFrame {
 };
 // bits of the device status word (DeviceBuffers::status): set by a kernel, turned into OW_ERR_HIP by the host at the next sync
 constexpr uint32_t kStatusRowSyncTimeout = 1u;  // a wave-pair rendezvous (RowSync, N = 2048) gave up waiting for its partner
+// one launch of ow_run's tick groups (k_tick_group_c_lp): pass 2 of d2 consecutive ticks and pass 1 of d1 later ticks
+constexpr int kMaxTickGroup = 4;  // (measured: 6 / 8 / 12 ticks per group gain another 8 / 12 / 15 % at 256^2 x 4 and nothing from 512^2 x 4 on)
+struct TickGroupArgs {
+    float time1[kMaxTickGroup][8];   // FP32-narrowed params.time of the d1 pass-1 ticks, per launch slot
+    int32_t tbase2[kMaxTickGroup];   // first scratch slot of each pass-2 tick
+    int32_t tbase1[kMaxTickGroup];   // ... of each pass-1 tick
+    int32_t slots, n2, n1, d2, d1;
+};
 // fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch
 constexpr int32_t kFaultRowSync = 1;
 constexpr int kMaxCascades = 8;

@@ -30,9 +30,12 @@ static int family(int slots, int mode) {
     if (mode == 4) return has_lp_compact ? 4 : 2;
     const long waves = (long)slots * N * plan_T(N) / 64;
     // measured crossovers (scripts/mode_bench.py).  Four-layer kernels (N = 128): layer-parallel up to 1024 waves.  Compact
-    // intermediate: layer-parallel from 256 waves (256^2 x 1 loses 3 % and stays on the four-layer pair) up to 1280
-    // (512^2 x 5: 32.8 vs 35.9 us; 512^2 x 6: 36.1 vs 35.2; 1024^2 x 2: 48.3 vs 39.3).
-    if (has_lp_compact && waves >= 256 && waves <= 1280) return 4;
+    // intermediate: layer-parallel from 256^2 x 1 (64 waves; on a single tick it ties with the four-layer pair, 11.8 vs 11.6 us, but
+    // ow_run's tick groups exist for this family only: 9.0 vs 11.6 us per tick) up to 1536 waves
+    // (round 2, scripts/pairs_crossover.py, us per tick of ow_run -- layer-parallel compact as tick pairs / one launch per pass
+    // against k_pass1c + k_pass2c: 512^2 x 5 27.1 / 30.9 vs 35.1; 512^2 x 6 28.6 / 33.8 vs 36.6; 512^2 x 8 41.6 / 42.8 vs 37.6;
+    // 1024^2 x 2 41.3 / 45.1 vs 39.7).
+    if (has_lp_compact && waves >= 64 && waves <= 1536) return 4;
     if (waves <= 1024) return 2;
     return has_compact ? kAutoLargeFamily : 1;
 }
@@ -91,6 +94,31 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
     if (buf.f32) launch(k_pass2<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     else launch(k_pass2<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args, DebugArgs{});
     return hipGetLastError();
+}
+
+// ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----
+template <int N, bool F32>
+static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s) {
+    using TP = TickPlan<N>;
+    g.n2 = g.d2 > 0 ? TP::items_2(g.slots) : 0;
+    g.n1 = TP::items_1(g.slots);
+    const int blocks = g.n2 + g.d1 * g.n1;
+    if (blocks < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_tick_group_c_lp<N, F32>), dim3(blocks), dim3(plan_lp_threads(N)), 0, s, buf, args, g);
+    return hipGetLastError();
+}
+bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s) {
+    if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
+#define OW_GROUP(NN) \
+    case NN: return buf.f32 ? launch_group_n<NN, true>(args, g, buf, s) : launch_group_n<NN, false>(args, g, buf, s);
+    switch (n) {
+        OW_GROUP(256)
+        OW_GROUP(512)
+        OW_GROUP(1024)
+    }
+#undef OW_GROUP
+    return hipErrorInvalidValue;
 }
 
 int kernel_family(int n, int slots, int mode) {

@@ -1110,9 +1110,11 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
 }
 
 // tau = thread index inside the item's plan_lp_threads(N) lanes; rows_lds = the item's plan_lp_rows(N) x 4 row regions
+// foam: the lane's four FP16 foam values (8 bytes).  foam_io & 1: load them from the foam plane first; & 2: store them back at the end
+// (a caller that runs consecutive ticks of the same rows keeps them in registers in between)
 template <int N, bool F32, int AUX_T, int AUX_O, class Issued, class WS>
 __device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds,
-                                               cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws) {
+                                               cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws, cplx &foam_bits, int foam_io = 3) {
     constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
     const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);  // which of F0..F3 this lane group transforms (wave-uniform)
     const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
@@ -1140,7 +1142,7 @@ __device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const C
         default: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 2, T_c); break;
     }
     if (g != 0) Pass2<N>::put_row0(d, t, gload8<AUX_T>(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
-    const cplx foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
+    if (foam_io & 1) foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
     ws.at(1, 0.0f);                     // loads issued
     issued();
     ws.at(3, d[15].x + foam_bits.x);    // the wave's own data has arrived
@@ -1169,7 +1171,8 @@ __device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const C
         fnew[q / 2] |= fh << (16 * (q & 1));
     }
     const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
-    gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, cplx{fn0, fn1});
+    foam_bits = cplx{fn0, fn1};
+    if (foam_io & 2) gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, foam_bits);
     ws.at(8, 0.0f);                     // unpacked, stores issued
 }
 
@@ -1194,11 +1197,106 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
     fetch_arguments(buf, cf);
     TwPrefetch<N> twp;
     tw_fetch<N>(twp, buf.tw);
+    cplx foam_bits;
     pass2c_lp_item<N, F32, AUX_T, AUX_O>(buf, cf, slot, row0, tau, tw_lds, rows_lds, rs, [&] {
         tw_commit<N>(twp, tw_lds);
         ws.at(2, tw_lds[0].x);          // table in LDS, block barrier passed
-    }, ws);
+    }, ws, foam_bits);
     ws.write(stamps, (plan_lp_threads(N) + 63) / 64, (unsigned long long)(tau / PER_LAYER));   // [14] = stores acknowledged
+}
+
+// ===================================================================================================
+// TICK GROUPS for ow_run on small batches (the layer-parallel compact family).  Pass 1 of a tick depends on the spectrum and the
+// time only, never on earlier results; pass 2 of a tick depends on its own pass 1 and, through the foam recurrence, on pass 2 of
+// the previous tick OF THE SAME ROWS.  So a run of ticks is launched in groups of D:
+//     [pass 1 of group 0]  [pass 2 of group 0 + pass 1 of group 1]  ...  [pass 2 of the last group]
+// where, inside one launch, a pass-2 block walks through the D ticks of its rows one after the other (foam stays in registers in
+// between) while other blocks do pass 1 of the next D ticks side by side.  K ticks cost K / D + 1 launches instead of 2 K, the
+// ~3 us of launch / first-fetch latency are paid once per D ticks, and a chip that one small tick cannot fill (256^2 x 4: one wave
+// per SIMD at best) is filled by D of them.  Nothing crosses blocks inside a launch -- the intermediates a launch reads were
+// finished by the previous launch -- and the scratch intermediate (T, pcol, rrow) holds 2 D ticks (tick t lives in slots
+// (t mod 2D) * count ...), so pass 1 writes where pass 2 of the launch before last read.  Per texel the arithmetic and its order are
+// those of the one-launch-per-pass kernels: results are bit-identical (tests/test_tick_groups.py).
+// Blocks [0, n2) are pass-2 items (each loops over d2 ticks), blocks [n2, n2 + d1 * n1) pass-1 items of d1 ticks (TickPlan: Q
+// side-by-side 8-row items per block, all of the same layer); d2 or d1 may be 0 (the two ends of a run).
+// ===================================================================================================
+template <int N>
+struct TickPlan {
+    static constexpr int Q = plan_lp_threads(N) / plan_wg_threads(N);  // pass-1 items side by side in one block
+    static constexpr int GPS = N / kWgRows;                            // 8-row groups per cascade
+    static_assert(Q >= 1 && plan_lp_threads(N) % plan_wg_threads(N) == 0 && (GPS / 2) % Q == 0, "block shapes of the two passes must nest");
+    static constexpr int full(int slots) { return slots * GPS / Q; }             // blocks of layer 0 (and of layer 2)
+    static constexpr int upper(int slots) { return slots * (GPS / 2) / Q; }      // blocks of layer 1 (upper half rows)
+    static constexpr int row0(int slots) { return (slots * 3 + Q - 1) / Q; }     // blocks of the three row-0 transforms
+    static constexpr int items_1(int slots) { return 2 * full(slots) + upper(slots) + row0(slots); }
+    static constexpr int items_2(int slots) { return slots * (N / plan_lp_rows(N)); }
+};
+
+template <int N, bool F32>
+__global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
+    using TP = TickPlan<N>;
+    constexpr int ROWS = plan_lp_rows(N), SUB = plan_wg_threads(N);
+    static_assert(!plan_row_spans_waves(N), "small-batch sizes only (N <= 1024)");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    RowSync<N> rs;
+    NoStamps ws;
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    if ((int)blockIdx.x < g.n2) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
+        const int item = blockIdx.x;
+        const int slot = item / (N / ROWS), row0 = (item % (N / ROWS)) * ROWS;
+        const CascadeFrame cf = args.c[slot];  // (pass 2 does not use the time)
+        fetch_arguments(buf, cf);
+        cplx foam_bits;
+        for (int j = 0; j < g.d2; ++j) {
+            const int tau = opaque((int)threadIdx.x);  // per tick: lane-derived offsets are recomputed, not carried around the loop
+            const int io = (j == 0 ? 1 : 0) | (j == g.d2 - 1 ? 2 : 0);
+            if (j == 0) {
+                pass2c_lp_item<N, F32, kAuxDefault, kAuxDefault>(buf, cf, g.tbase2[0] + slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, ws,
+                                                                 foam_bits, io);
+            } else {
+                lds_barrier();  // the previous tick's LDS reads are done
+                pass2c_lp_item<N, F32, kAuxDefault, kAuxDefault>(buf, cf, g.tbase2[j] + slot, row0, tau, tw_lds, rows_lds, rs, [] {}, ws, foam_bits, io);
+            }
+        }
+        return;
+    }
+    // ---- pass 1: tick j of the later group, Q items of one layer side by side ----
+    const int b1 = (int)blockIdx.x - g.n2, j = b1 / g.n1, item = b1 % g.n1;
+    const int tau = threadIdx.x;
+    const int sub = __builtin_amdgcn_readfirstlane(tau / SUB), tau_sub = tau % SUB;
+    const int n_full = TP::full(g.slots), n_upper = TP::upper(g.slots);
+    int L, slot, row0;
+    bool active = true;
+    if (item < 2 * n_full) {  // layers 0 and 2: every 8-row group
+        L = item < n_full ? 0 : 2;
+        const int group = (item < n_full ? item : item - n_full) * TP::Q + sub;
+        slot = group / TP::GPS;
+        row0 = (group % TP::GPS) * kWgRows;
+    } else if (item < 2 * n_full + n_upper) {  // layer 1: the upper half of the rows
+        L = 1;
+        const int group = (item - 2 * n_full) * TP::Q + sub;
+        slot = group / (TP::GPS / 2);
+        row0 = N / 2 + (group % (TP::GPS / 2)) * kWgRows;
+    } else {  // the three extra transforms of texel row 0, one (slot, Q) pair per 8-row sub-block
+        const int r = (item - 2 * n_full - n_upper) * TP::Q + sub;
+        active = r < g.slots * 3;
+        slot = active ? r / 3 : 0;
+        L = 3 + (active ? r % 3 : 0);
+        row0 = 0;
+    }
+    // (an idle sub-block of a row-0 item still takes part in the table's block barrier; the row-0 path has no other block barrier,
+    //  and in the layer paths every sub-block of the block is active)
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    if (active) {
+        pass1c_lp_item<N, kAuxDefault>(buf, cf, g.time1[j][slot], g.tbase1[j] + slot, row0, L, tau_sub, tw_lds, rows_lds + sub * kWgRows * plan_region_cplx(N),
+                                       rs, [&] { tw_commit<N>(twp, tw_lds); }, ws);
+    } else {
+        tw_commit<N>(twp, tw_lds);
+    }
 }
 
 }  // namespace ow

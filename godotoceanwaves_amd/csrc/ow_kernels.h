@@ -55,4 +55,10 @@ hipError_t launch_pass1(int n, int slots, int mode, const FrameArgs &args, const
 hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const DeviceBuffers &buf, hipStream_t s,
                         const LaunchTiming &lt = LaunchTiming{});
 
+// Tick groups for ow_run on small batches (ow_frame_kernels.h k_tick_group_c_lp): pass 2 of g.d2 consecutive ticks (scratch slots
+// g.tbase2[j] + i) and / or pass 1 of g.d1 later ticks (times g.time1[j][i], scratch slots g.tbase1[j] + i) in one launch; n2 / n1 are
+// filled in by the launcher.
+bool tick_groups_supported(int n);
+hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s);
+
 }  // namespace ow

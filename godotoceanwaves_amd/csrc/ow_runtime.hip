@@ -65,6 +65,9 @@ struct ow_context {
     // device-side spin that gave up), every synchronising entry point turns a non-zero word into OW_ERR_HIP
     uint32_t *status_host = nullptr;
     uint32_t inject_fault = 0;  // ow_debug_inject_fault: applied to the next batch only
+    // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
+    // into one group; the scratch buffers hold 2 * depth * count cascades then
+    int group_max_count = 0, group_depth = 0;
     // timing: a pool of events so that timed ticks stay enqueued back to back
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 4 per timed batch: start/stop of the pass-1 dispatch, start/stop of the pass-2 dispatch
@@ -107,6 +110,22 @@ int batch_size(const ow_context *c, int count) {
     const int cap = std::max(1, (int)(kBatchTexels / pl)), batches = (count + cap - 1) / cap;
     return (count + batches - 1) / batches;
 }
+
+// ow_run on a batch of the layer-parallel compact family goes out in tick groups (k_tick_group_c_lp), which need the scratch
+// intermediate 2 * depth times.  Largest cascade count served for this context, and the depth that fits kGroupScratchBytes:
+constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
+void plan_tick_groups(ow_context *c, uint32_t flags) {
+    c->group_max_count = c->group_depth = 0;
+    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n) || (c->kernel_mode != 0 && c->kernel_mode != 4)) return;
+    int best = 0;
+    for (int count = 1; count <= c->cascades; ++count)
+        if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;
+    if (best == 0) return;
+    const size_t per_tick = (size_t)best * c->n * c->n * ow::kLayers * sizeof(ow::cplx);
+    c->group_max_count = best;
+    c->group_depth = (int)std::min<size_t>(ow::kMaxTickGroup, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
+}
+int scratch_slots(const ow_context *c) { return std::max(std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count); }
 
 constexpr size_t kMaxTimedBatches = 4096;
 
@@ -324,7 +343,8 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
-    OW_ALLOC(c->buf.T, (size_t)std::min((int)L, max_batch(c)) * pl * ow::kLayers * sizeof(ow::cplx));
+    plan_tick_groups(c, cfg->flags);
+    OW_ALLOC(c->buf.T, (size_t)scratch_slots(c) * pl * ow::kLayers * sizeof(ow::cplx));
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -340,7 +360,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
     if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
     {   // side buffers of the compact intermediate, one batch worth like T
-        const size_t slots = (size_t)std::min((int)L, max_batch(c));
+        const size_t slots = (size_t)scratch_slots(c);
         OW_ALLOC(c->buf.pcol, slots * c->n * sizeof(ow::cplx));
         OW_ALLOC(c->buf.rrow, slots * c->n * 4 * sizeof(ow::cplx));
     }
@@ -477,9 +497,105 @@ ow_status ow_debug_inject_fault(ow_context *c, uint32_t fault_bits) {
     return OW_OK;
 }
 
+namespace {
+
+// Can the remaining ticks of ow_run go out as tick groups?  Only a batch of the layer-parallel compact family, with nothing left
+// armed, no spectrum to regenerate, no fault to inject, no per-launch timing requested, and records that pass enqueue()'s checks.
+bool tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
+    if (c->group_max_count == 0 || count > c->group_max_count || c->timing || c->inject_fault || c->pass_num_cascades_remaining != 0) return false;
+    if (ow::kernel_family(c->n, count, c->kernel_mode) != 4) return false;
+    for (int i = 0; i < count; ++i)
+        if (params[i].should_generate_spectrum || !finite_record(params[i]) || !(params[i].tile_length[0] > 0.0f) || !(params[i].tile_length[1] > 0.0f))
+            return false;  // (the ordinary path regenerates / reports)
+    return true;
+}
+
+// one more ow_update_all() worth of arithmetic on the records (wave_generator.gd:101-106); time_out[i] = FP32 time of launch
+// slot i (= cascade count-1-i, as in ow_update_all)
+void advance_tick(double delta, ow_cascade_params *params, int count, float *time_out) {
+    for (int i = 0; i < count; ++i) {
+        ow_cascade_params &p = params[count - 1 - i];
+        p.time += delta;
+        p.foam_grow_rate = delta * (double)p.foam_amount * 7.5;
+        const double d = 10.0 - (double)p.foam_amount;
+        p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
+        time_out[i] = (float)p.time;
+    }
+}
+
+// `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
+//   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
+ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
+    const int D = c->group_depth, groups = (ticks + D - 1) / D;
+    auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
+    auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
+    ow::TickGroupArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.slots = count;
+    // pass 1 of group 0
+    ga.d2 = 0;
+    ga.d1 = group_size(0);
+    for (int j = 0; j < ga.d1; ++j) {
+        advance_tick(delta, params, count, ga.time1[j]);
+        ga.tbase1[j] = slot_of_tick(j);
+    }
+    // the launch constants that do not change from tick to tick (same delta: same foam rates), launch slot i = cascade count-1-i
+    ow::FrameArgs args;
+    std::memset(&args, 0, sizeof(args));
+    for (int i = 0; i < count; ++i) {
+        const ow_cascade_params &p = params[count - 1 - i];
+        ow::CascadeFrame &cf = args.c[i];
+        cf.tile_x = p.tile_length[0];
+        cf.tile_y = p.tile_length[1];
+        cf.whitecap = p.whitecap;
+        cf.foam_grow_rate = (float)p.foam_grow_rate;
+        cf.foam_decay = expf(-(float)p.foam_decay_rate);
+        cf.cascade = count - 1 - i;
+    }
+    OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream));
+    for (int g = 0; g < groups; ++g) {
+        ga.d2 = group_size(g);
+        for (int j = 0; j < ga.d2; ++j) ga.tbase2[j] = slot_of_tick(g * D + j);
+        ga.d1 = g + 1 < groups ? group_size(g + 1) : 0;
+        for (int j = 0; j < ga.d1; ++j) {
+            advance_tick(delta, params, count, ga.time1[j]);
+            ga.tbase1[j] = slot_of_tick((g + 1) * D + j);
+        }
+        OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream));
+    }
+    for (int i = 0; i < count; ++i) {
+        c->pass_parameters[i] = params[i];
+        args.c[i].time = (float)params[count - 1 - i].time;
+    }
+    c->pass_count = count;
+    c->pass_num_cascades_remaining = 0;
+    c->last_args = args;
+    c->last_count = count;
+    c->last_family = 5;
+    for (int &sl : c->slot_of) sl = -1;  // (no reference-layout intermediate to inspect after such a run)
+    return OW_OK;
+}
+
+}  // namespace
+
 ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
     if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
-    for (int f = 0; f < frames; ++f) {
+    if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+    int f = 0;
+    // the first tick always takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
+    if (frames >= 1) {
+        ow_status st = ow_update_all(c, delta, params, count);
+        if (st != OW_OK) return st;
+        f = 1;
+    }
+    // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
+    if (frames - f >= 2 && std::isfinite(delta) && tick_groups_usable(c, params, count)) {
+        OW_HIP(hipSetDevice(c->device));
+        ow_status st = run_tick_groups(c, delta, params, count, frames - f);
+        if (st != OW_OK) return st;
+        f = frames;
+    }
+    for (; f < frames; ++f) {
         ow_status st = ow_update_all(c, delta, params, count);
         if (st != OW_OK) return st;
     }
@@ -488,6 +604,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
 
 int32_t ow_last_kernel_family(const ow_context *c) { return c ? c->last_family : 0; }
 int32_t ow_last_batch_cascades(const ow_context *c) { return c ? c->last_count : 0; }
+int32_t ow_tick_group_depth(const ow_context *c) { return c ? c->group_depth : 0; }
 
 int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_cascades_remaining : 0; }
 

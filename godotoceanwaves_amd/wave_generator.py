@@ -11,8 +11,8 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_COMPACT, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, ow_cascade_params,
-                   ow_config)
+from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_COMPACT, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, OW_FLAG_NO_TICK_GROUPS,
+                   ow_cascade_params, ow_config)
 
 G = 9.81       # wave_generator.gd:5
 DEPTH = 20.0   # wave_generator.gd:6
@@ -101,6 +101,7 @@ class WaveGenerator:
         self.depth = DEPTH
         self.debug_f32 = False
         self.kernels = None           # None = runtime picks per batch; "standard" / "layer_parallel" pin the kernel family
+        self.tick_groups = True        # False: run() keeps one pair of launches per tick (OW_FLAG_NO_TICK_GROUPS)
         self.device_id = -1
         self.stream = None
         self.external_maps = (None, None)  # optional caller-owned device buffers (displacement, normal)
@@ -117,7 +118,7 @@ class WaveGenerator:
             self.free()
         cfg = ow_config(map_size=int(self.map_size), num_cascades=int(num_cascades), device_id=self.device_id,
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
-                        normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) |
+                        normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) | (0 if self.tick_groups else OW_FLAG_NO_TICK_GROUPS) |
                         {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL,
                                "compact": OW_FLAG_KERNELS_COMPACT,
                                "layer_parallel_compact": OW_FLAG_KERNELS_LAYER_PARALLEL | OW_FLAG_KERNELS_COMPACT}[self.kernels])
@@ -269,7 +270,7 @@ class WaveGenerator:
         _lib.check(self._lib.ow_get_intermediate(self.context, cascade, out.ctypes.data))
         return out
 
-    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact", 4: "layer_parallel_compact"}
+    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact", 4: "layer_parallel_compact", 5: "tick_groups_compact"}
 
     def last_kernel_family(self):
         """which kernels the most recent batch ran with: "standard", "layer_parallel", "compact" (None before the first launch)"""
@@ -278,6 +279,10 @@ class WaveGenerator:
     def last_batch_cascades(self):
         """cascades in the most recent pair of launches (a tick may be split into several pairs)"""
         return int(self._lib.ow_last_batch_cascades(self.context))
+
+    def tick_group_depth(self):
+        """ticks per launch of run() on a small batch (0: this context never uses tick groups)"""
+        return int(self._lib.ow_tick_group_depth(self.context))
 
     def timing(self, enable):
         _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))

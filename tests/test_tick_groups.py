@@ -1,0 +1,88 @@
+"""ow_run on a small batch: from the second tick on, pass 2 of tick k and pass 1 of tick k + 1 go out in ONE launch (k_tick_group_c_lp;
+the two are independent, the scratch intermediate is double-buffered by tick parity) -- against the same ticks as one pair of
+launches each.  Same lane code in the same order per texel, so the comparison is BITWISE; the golden 1000-frame loop
+(tests/test_golden.py, BASELINE config C2) runs through the tick groups as well and holds them to the oracle's trajectory."""
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator
+from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, ids, tick_groups, debug=False):
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.tick_groups = tick_groups
+    gen.debug_f32 = debug
+    gen.init_gpu(max(2, len(ids)))
+    return gen, [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+
+
+def same_maps(a, b, count):
+    for i in range(count):
+        da, na = a.get_maps(i)
+        db, nb = b.get_maps(i)
+        assert np.array_equal(da.view(np.uint16), db.view(np.uint16)), i
+        assert np.array_equal(na.view(np.uint16), nb.view(np.uint16)), i
+
+
+@pytest.mark.parametrize("n,ids", [(256, [0, 1, 2, 3]), (256, [0, 1, 2, 3, 4, 5, 6, 7]), (512, [2]), (512, [0, 1, 2, 3]), (1024, [1])])
+@pytest.mark.parametrize("frames", [2, 3, 4, 17, 40])
+def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames):
+    a, pa = make(n, ids, True)
+    b, pb = make(n, ids, False)
+    a.run(UPDATE_DELTA, pa, frames)
+    b.run(UPDATE_DELTA, pb, frames)
+    a.sync(); b.sync()
+    assert a.last_kernel_family() == ("tick_groups_compact" if frames >= 3 else "layer_parallel_compact")
+    assert b.last_kernel_family() == "layer_parallel_compact"
+    same_maps(a, b, len(ids))
+    for x, y in zip(pa, pb):
+        assert x.time == y.time and x.foam_grow_rate == y.foam_grow_rate and x.foam_decay_rate == y.foam_decay_rate
+        assert not x.should_generate_spectrum
+    # ... and the state carries on seamlessly on either path (foam plane, times, scratch halves)
+    a.update_all(UPDATE_DELTA, pa); b.update_all(UPDATE_DELTA, pb)
+    a.run(UPDATE_DELTA, pa, 6); b.run(UPDATE_DELTA, pb, 6)
+    a.sync(); b.sync()
+    same_maps(a, b, len(ids))
+
+
+def test_tick_groups_match_the_oracle_and_keep_the_debug_channels():
+    n, ids, frames = 256, [0, 1, 2, 3], 6
+    gen, params = make(n, ids, True, debug=True)
+    og = H.oracle_generator(n, ids)
+    gen.run(UPDATE_DELTA, params, frames)
+    for _ in range(frames):
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == "tick_groups_compact"
+    for i in range(len(ids)):
+        assert params[i].time == og.params[i].time
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
+
+
+def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
+    """live parameter edits regenerate the spectrum through the ordinary first tick; batches outside the small-batch family never enter"""
+    n, ids = 256, [0, 1, 2, 3]
+    a, pa = make(n, ids, True)
+    b, pb = make(n, ids, False)
+    a.run(UPDATE_DELTA, pa, 4); b.run(UPDATE_DELTA, pb, 4)
+    pa[2].wind_speed = 7.0; pb[2].wind_speed = 7.0
+    a.run(UPDATE_DELTA, pa, 4); b.run(UPDATE_DELTA, pb, 4)
+    a.sync(); b.sync()
+    assert a.last_kernel_family() == "tick_groups_compact"
+    same_maps(a, b, len(ids))
+    big, pbig = make(1024, [0, 1], True)
+    big.run(UPDATE_DELTA, pbig, 4)
+    big.sync()
+    assert big.last_kernel_family() == "compact"

@@ -156,7 +156,7 @@ int main(int argc, char **argv) {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, dev));
         using TP = TickPlan<N>;
-        const int grid = std::min(std::max(TP::items_a(C), TP::items_b(C)), per_cu * prop.multiProcessorCount);
+        const int grid = std::min(std::max(TP::items_1(C), TP::items_2(C)), per_cu * prop.multiProcessorCount);
         TickTimes times{};
         for (int k = 0; k < kMaxTicksPerLaunch; ++k)
             for (int i = 0; i < C; ++i) times.t[k][i] = 120.5f + i + 0.02f * k;
@@ -169,7 +169,7 @@ int main(int argc, char **argv) {
         };
         const float per_launch = time_it(loop, std::max(20, iters / 16), s);
         printf("tick loop: %d blocks (%d per CU possible), %d phase-A items, %d phase-B items: %7.2f us per launch of %d ticks = %6.2f us per tick\n", grid, per_cu,
-               TP::items_a(C), TP::items_b(C), per_launch, ticks, per_launch / ticks);
+               TP::items_1(C), TP::items_2(C), per_launch, ticks, per_launch / ticks);
         unsigned st_word = 0;
         CK(hipMemcpy(&st_word, buf.status, 4, hipMemcpyDeviceToHost));
         printf("status word after the tick loops: 0x%x\n", st_word);

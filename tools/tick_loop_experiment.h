@@ -62,19 +62,6 @@ __device__ __forceinline__ bool grid_rendezvous(unsigned *counter, unsigned targ
     return ok;
 }
 
-// number of items of the two phases for `slots` cascades
-template <int N>
-struct TickPlan {
-    static constexpr int Q = plan_lp_threads(N) / plan_wg_threads(N);  // pass-1 items side by side in one block
-    static constexpr int GPS = N / kWgRows;                            // 8-row groups per cascade
-    static_assert(Q >= 1 && plan_lp_threads(N) % plan_wg_threads(N) == 0 && (GPS / 2) % Q == 0, "block shapes of the two passes must nest");
-    static constexpr int full(int slots) { return slots * GPS / Q; }             // blocks of layer 0 (and of layer 2)
-    static constexpr int upper(int slots) { return slots * (GPS / 2) / Q; }      // blocks of layer 1 (upper half rows)
-    static constexpr int row0(int slots) { return (slots * 3 + Q - 1) / Q; }     // blocks of the three row-0 transforms
-    static constexpr int items_a(int slots) { return 2 * full(slots) + upper(slots) + row0(slots); }
-    static constexpr int items_b(int slots) { return slots * (N / plan_lp_rows(N)); }
-};
-
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_ticks_c_lp(DeviceBuffers buf, FrameArgs args, TickTimes times, int slots, int ticks,
                                                                           unsigned *counter, unsigned counter_base) {
@@ -87,7 +74,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_ticks_c_lp(DeviceBuff
     RowSync<N> rs;
     NoStamps ws;
     load_twiddles<N>(tw_lds, buf.tw);  // once per launch
-    const int items_a = TP::items_a(slots), items_b = TP::items_b(slots);
+    const int items_a = TP::items_1(slots), items_b = TP::items_2(slots);
     const int n_full = TP::full(slots), n_upper = TP::upper(slots);
     bool alive = true, first = true;
     for (int k = 0; k < ticks; ++k) {
@@ -132,7 +119,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_ticks_c_lp(DeviceBuff
             first = false;
             const int slot = item / (N / ROWS), row0 = (item % (N / ROWS)) * ROWS;
             CascadeFrame cf = args.c[slot];
-            pass2c_lp_item<N, F32, kAuxAgent, kAuxDefault>(buf, cf, tbase + slot, row0, tau, tw_lds, rows_lds, rs, [] {}, ws);
+            cplx foam_bits;
+            pass2c_lp_item<N, F32, kAuxAgent, kAuxDefault>(buf, cf, tbase + slot, row0, tau, tw_lds, rows_lds, rs, [] {}, ws, foam_bits);
         }
     }
 }
