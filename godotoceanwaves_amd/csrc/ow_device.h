@@ -523,6 +523,52 @@ struct CascadeFrame {
 };
 // bits of the device status word (DeviceBuffers::status): set by a kernel, turned into OW_ERR_HIP by the host at the next sync
 constexpr uint32_t kStatusRowSyncTimeout = 1u;  // a wave-pair rendezvous (RowSync, N = 2048) gave up waiting for its partner
+// layer-parallel pass 2: a block = plan_lp_rows(N) rows x 4 lane groups (one per transform) x N/16 lanes (512 threads)
+constexpr int plan_lp_rows(int N) { return 128 / plan_T(N) > 0 ? 128 / plan_T(N) : 1; }
+constexpr int plan_lp_threads(int N) { return plan_lp_rows(N) * kLayers * plan_T(N); }
+constexpr int plan_lp_lds_cplx(int N) { return plan_region_cplx(N) * plan_lp_rows(N) * kLayers + plan_tw_total(N); }
+
+// Work items of the tick-group kernel (k_tick_group_c_lp) for `slots` cascades.  Pass 2: one item = plan_lp_rows(N) rows.  Pass 1:
+// one item = one BLOCK of Q side-by-side 8-row sub-items, all of the same kind, so that the block barriers inside the layer path
+// stay uniform: layer 0 and layer 2 over every 8-row group, layer 1 over the groups of the upper half of the rows (the lower
+// half's hz is the conjugate of the mirrored rows'), and the three extra transforms L = 3..5 of texel row 0 of every cascade.
+template <int N>
+struct TickPlan {
+    static constexpr int Q = plan_lp_threads(N) / plan_wg_threads(N);  // pass-1 sub-items side by side in one block
+    static constexpr int GPS = N / kWgRows;                            // 8-row groups per cascade
+    static_assert(Q >= 1 && plan_lp_threads(N) % plan_wg_threads(N) == 0 && (GPS / 2) % Q == 0, "block shapes of the two passes must nest");
+    static constexpr int full(int slots) { return slots * GPS / Q; }             // blocks of layer 0 (and of layer 2)
+    static constexpr int upper(int slots) { return slots * (GPS / 2) / Q; }      // blocks of layer 1 (upper half rows)
+    static constexpr int row0(int slots) { return (slots * 3 + Q - 1) / Q; }     // blocks of the three row-0 transforms
+    static constexpr int items_1(int slots) { return 2 * full(slots) + upper(slots) + row0(slots); }
+    static constexpr int items_2(int slots) { return slots * (N / plan_lp_rows(N)); }
+    // sub-item `sub` (0..Q-1) of pass-1 item `item`: which (layer / row-0 transform L, launch slot, first row); false = this
+    // sub-block has nothing to do (only in the last row-0 item)
+    static OW_HD bool decode(int item, int sub, int slots, int &L, int &slot, int &row0) {
+        const int n_full = full(slots), n_upper = upper(slots);
+        if (item < 2 * n_full) {  // layers 0 and 2: every 8-row group
+            L = item < n_full ? 0 : 2;
+            const int group = (item < n_full ? item : item - n_full) * Q + sub;
+            slot = group / GPS;
+            row0 = (group % GPS) * kWgRows;
+            return true;
+        }
+        if (item < 2 * n_full + n_upper) {  // layer 1: the upper half of the rows
+            L = 1;
+            const int group = (item - 2 * n_full) * Q + sub;
+            slot = group / (GPS / 2);
+            row0 = N / 2 + (group % (GPS / 2)) * kWgRows;
+            return true;
+        }
+        const int r = (item - 2 * n_full - n_upper) * Q + sub;  // the three extra transforms of texel row 0, one (slot, L) per sub-block
+        const bool active = r < slots * 3;
+        slot = active ? r / 3 : 0;
+        L = 3 + (active ? r % 3 : 0);
+        row0 = 0;
+        return active;
+    }
+};
+
 // one launch of ow_run's tick groups (k_tick_group_c_lp): pass 2 of d2 consecutive ticks and pass 1 of d1 later ticks
 constexpr int kMaxTickGroup = 4;  // (measured: 6 / 8 / 12 ticks per group gain another 8 / 12 / 15 % at 256^2 x 4 and nothing from 512^2 x 4 on)
 struct TickGroupArgs {

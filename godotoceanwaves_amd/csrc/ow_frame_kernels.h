@@ -946,9 +946,6 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1_lp(DeviceBuffer
 // PASS 2, layer-parallel: a block = plan_lp_rows(N) rows x 4 layers x N/16 lanes (512 threads).  Every (row, layer)
 // lane group transforms its layer, leaves it in its LDS region in natural order, and after one block barrier each
 // layer group finishes a quarter of the row's texels (fft_unpack.glsl for texels o = 4g .. 4g+3 of every lane).
-constexpr int plan_lp_rows(int N) { return 128 / plan_T(N) > 0 ? 128 / plan_T(N) : 1; }
-constexpr int plan_lp_threads(int N) { return plan_lp_rows(N) * kLayers * plan_T(N); }
-constexpr int plan_lp_lds_cplx(int N) { return plan_region_cplx(N) * plan_lp_rows(N) * kLayers + plan_tw_total(N); }
 
 template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
 __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2_lp(DeviceBuffers buf, FrameArgs args) {
@@ -1220,18 +1217,6 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
 // Blocks [0, n2) are pass-2 items (each loops over d2 ticks), blocks [n2, n2 + d1 * n1) pass-1 items of d1 ticks (TickPlan: Q
 // side-by-side 8-row items per block, all of the same layer); d2 or d1 may be 0 (the two ends of a run).
 // ===================================================================================================
-template <int N>
-struct TickPlan {
-    static constexpr int Q = plan_lp_threads(N) / plan_wg_threads(N);  // pass-1 items side by side in one block
-    static constexpr int GPS = N / kWgRows;                            // 8-row groups per cascade
-    static_assert(Q >= 1 && plan_lp_threads(N) % plan_wg_threads(N) == 0 && (GPS / 2) % Q == 0, "block shapes of the two passes must nest");
-    static constexpr int full(int slots) { return slots * GPS / Q; }             // blocks of layer 0 (and of layer 2)
-    static constexpr int upper(int slots) { return slots * (GPS / 2) / Q; }      // blocks of layer 1 (upper half rows)
-    static constexpr int row0(int slots) { return (slots * 3 + Q - 1) / Q; }     // blocks of the three row-0 transforms
-    static constexpr int items_1(int slots) { return 2 * full(slots) + upper(slots) + row0(slots); }
-    static constexpr int items_2(int slots) { return slots * (N / plan_lp_rows(N)); }
-};
-
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
     using TP = TickPlan<N>;
@@ -1267,26 +1252,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
     const int b1 = (int)blockIdx.x - g.n2, j = b1 / g.n1, item = b1 % g.n1;
     const int tau = threadIdx.x;
     const int sub = __builtin_amdgcn_readfirstlane(tau / SUB), tau_sub = tau % SUB;
-    const int n_full = TP::full(g.slots), n_upper = TP::upper(g.slots);
     int L, slot, row0;
-    bool active = true;
-    if (item < 2 * n_full) {  // layers 0 and 2: every 8-row group
-        L = item < n_full ? 0 : 2;
-        const int group = (item < n_full ? item : item - n_full) * TP::Q + sub;
-        slot = group / TP::GPS;
-        row0 = (group % TP::GPS) * kWgRows;
-    } else if (item < 2 * n_full + n_upper) {  // layer 1: the upper half of the rows
-        L = 1;
-        const int group = (item - 2 * n_full) * TP::Q + sub;
-        slot = group / (TP::GPS / 2);
-        row0 = N / 2 + (group % (TP::GPS / 2)) * kWgRows;
-    } else {  // the three extra transforms of texel row 0, one (slot, Q) pair per 8-row sub-block
-        const int r = (item - 2 * n_full - n_upper) * TP::Q + sub;
-        active = r < g.slots * 3;
-        slot = active ? r / 3 : 0;
-        L = 3 + (active ? r % 3 : 0);
-        row0 = 0;
-    }
+    const bool active = TP::decode(item, sub, g.slots, L, slot, row0);
     // (an idle sub-block of a row-0 item still takes part in the table's block barrier; the row-0 path has no other block barrier,
     //  and in the layer paths every sub-block of the block is active)
     const CascadeFrame cf = args.c[slot];

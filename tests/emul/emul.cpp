@@ -314,7 +314,34 @@ void frame_compact(const float *h0a, const float *omega, CascadeFrame cf, float 
 
 }  // namespace
 
+// every (L, slot, row0) the tick-group kernel's pass-1 item decode hands out for `slots` cascades: 3 ints per entry, returns the count
+template <int N>
+static int tick_items(int slots, int *out) {
+    using TP = TickPlan<N>;
+    int cnt = 0;
+    for (int item = 0; item < TP::items_1(slots); ++item)
+        for (int sub = 0; sub < TP::Q; ++sub) {
+            int L, slot, row0;
+            if (!TP::decode(item, sub, slots, L, slot, row0)) continue;
+            out[3 * cnt] = L;
+            out[3 * cnt + 1] = slot;
+            out[3 * cnt + 2] = row0;
+            ++cnt;
+        }
+    return cnt;
+}
+
 extern "C" {
+int emul_tick_items(int n, int slots, int *out) {
+    switch (n) {
+        case 256: return tick_items<256>(slots, out);
+        case 512: return tick_items<512>(slots, out);
+        case 1024: return tick_items<1024>(slots, out);
+    }
+    return -1;
+}
+int emul_tick_items_2(int n, int slots) { return n == 256 ? TickPlan<256>::items_2(slots) : n == 512 ? TickPlan<512>::items_2(slots) : TickPlan<1024>::items_2(slots); }
+
 
 int emul_rows_fft(int n, const float *in, float *out, int rows) {
     switch (n) {

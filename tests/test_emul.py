@@ -112,3 +112,25 @@ def test_emulated_kernels_match_oracle(emul, n, ci, intermediate):
                 assert H.relmax(f32[..., c], ref[..., c]) < 5e-6, (frame, name)
         assert H.fp16_close(disp, g.displacement(0)) <= 1.0
         assert H.fp16_close(norm[..., :3], g.normal(0)[..., :3]) <= 1.0
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024])
+@pytest.mark.parametrize("slots", [1, 3, 4, 8])
+def test_tick_group_items_cover_every_row_group_exactly_once(emul, n, slots):
+    """ow_run's tick groups (k_tick_group_c_lp): the pass-1 item decode (TickPlan::decode, compiled here as plain C++) hands out, for
+    every cascade, layer 0 and layer 2 of every 8-row group, layer 1 of the upper-half groups only, and the three row-0 transforms --
+    each exactly once; pass 2 has one item per plan_lp_rows rows."""
+    out = np.zeros((slots * (n // 8) * 4 + 64, 3), np.int32)
+    emul.emul_tick_items.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(np.int32, flags="C")]
+    cnt = emul.emul_tick_items(n, slots, out)
+    got = sorted(map(tuple, out[:cnt].tolist()))
+    want = []
+    for s_ in range(slots):
+        for g in range(n // 8):
+            want += [(0, s_, 8 * g), (2, s_, 8 * g)]
+            if 8 * g >= n // 2:
+                want.append((1, s_, 8 * g))
+        want += [(3, s_, 0), (4, s_, 0), (5, s_, 0)]
+    assert got == sorted(want)
+    rows_per_item = max(1, 128 // (n // 16))
+    assert emul.emul_tick_items_2(n, slots) == slots * n // rows_per_item
