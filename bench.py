@@ -239,12 +239,14 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         # moves both passes' bytes of GROUP (= ow_tick_group_depth) ticks.  (p1 / p2 below are the one-launch-per-pass kernels of the same tick, probed after.)
         GROUP = max(1, group_depth)
         dom, dom_ms = "k_tick_group_c_lp", elapsed / args.steps * 1e3 * GROUP
-        dom_bpt, dom_contract, texels = (k1 + k2) * GROUP, sum(CONTRACT_BYTES) * GROUP, n * n * C
+        # (foam is read before the first and written after the last of the GROUP ticks only: 4 B/texel less for each tick in between)
+        dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C
         per_launch = C
     achieved = gbps(dom_bpt * texels, dom_ms)  # (grouped: texels of one tick x bytes of GROUP ticks)
     contract = gbps(dom_contract * texels, dom_ms)
     tick_s = elapsed / args.steps
-    tick_moved = (k1 + k2) * n * n * C / tick_s / 1e9          # per GPU
+    tick_bpt = (dom_bpt / max(1, group_depth)) if grouped else (k1 + k2)
+    tick_moved = tick_bpt * n * n * C / tick_s / 1e9          # per GPU
     tick_contract = sum(CONTRACT_BYTES) * n * n * C / tick_s / 1e9
     traffic = None if grouped else pmc_traffic(dom, n, per_launch)
     headline = (n, C) == (1024, 4)
@@ -291,7 +293,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             "traffic_gbps": round(gbps(traffic, dom_ms), 1) if traffic else None,
             "avg_launch_ms": round(dom_ms, 5), "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
-            "tick": {"bytes_per_texel": k1 + k2, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
+            "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
                      "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},
         },
