@@ -54,7 +54,7 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
     }
     if constexpr (plan_split(N)) {
         if (fam == 3) {  // a row spans two waves: the split plan (one wave per parity, no rendezvous in pass 1)
-            launch(k_pass1c_split<N>, dim3(blocks * (kWgRows / OW_SPLIT_P1_ROWS)), dim3(SplitGeo<N, OW_SPLIT_P1_ROWS>::kThreads), s, lt, buf, args);
+            launch(k_pass1c_split<N, OW_SPLIT_P1_ROWS>, dim3(blocks * (kWgRows / OW_SPLIT_P1_ROWS)), dim3(SplitGeo<N, OW_SPLIT_P1_ROWS>::kThreads), s, lt, buf, args);
             return hipGetLastError();
         }
     }
@@ -86,8 +86,13 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
     const int blocks = slots * (N / kWgRows);
     if constexpr (plan_T(N) >= 16) {
         if (fam == 3) {
-            if (buf.f32) launch(k_pass2c<N, true>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
-            else launch(k_pass2c<N, false>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            // The two output maps are stored non-temporally: they are write-only streams of 16 B/texel that nothing on the device
+            // reads back soon, and left to the default policy they push the spectra and the intermediate out of the 256 MiB Infinity
+            // Cache as soon as a tick's working set exceeds it (round 2, same box: 2048^2 x 4 303 -> 272 us per tick, 1024^2 x 8
+            // 124 -> 115, 512^2 x 8 38.0 -> 35.1; 1024^2 x 4, which fits, 57.1 -> 57.2).  nt on the T loads -- T is dead after
+            // this pass -- loses (1024^2 x 4: 61.1), sc1 on the outputs changes nothing, nt on the T stores of pass 1 loses (2048^2 x 4: 307).
+            if (buf.f32) launch(k_pass2c<N, true, kAuxDefault, kAuxNT>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
+            else launch(k_pass2c<N, false, kAuxDefault, kAuxNT>, dim3(blocks), dim3(plan_wg_threads(N)), s, lt, buf, args);
             return hipGetLastError();
         }
     }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-2 visit 6 (after the non-temporal output stores): full GPU suite, sweep, default bench, kernel traces of 2048^2 x 4 and 1024^2 x 8, PMC 2048
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest.log; tail -3 gpurun_out/pytest.log
+timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log | cut -c1-260
+rm -f gpurun_out/sweep.jsonl
+timeout 900 python bench.py --sweep --sweep-out gpurun_out/sweep.jsonl --steps 1000 --warmup 100 > gpurun_out/sweep.log 2>&1; echo "sweep exit $?"
+python - <<'PY'
+import json
+for l in open('gpurun_out/sweep.jsonl'):
+    d=json.loads(l); r=d['roofline']
+    print(d['config']['map_size'], d['config']['cascades_per_gpu'], 'maps/s', d['value'], 'ms/tick', d['ms_per_step'], r['kernel'], 'frac', r['frac'], 'tick frac', r['tick']['frac'], 'copy', r['tick']['frac_of_copy_ceiling'], 'p1', r['pass1_ms'], 'p2', r['pass2_ms'], 'cpu', d['cpu_baseline']['value'])
+PY
+for cfg in "2048 4" "1024 8"; do set -- $cfg
+  rm -rf gpurun_out/prof_r02c_$1x$2
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_r02c_$1x$2" -o t -- python "$GRAFT_REPO_ROOT/scripts/drive.py" --map-size $1 --cascades $2 --frames 400 --warmup 100) > gpurun_out/prof_r02c_$1x$2.log 2>&1
+  python scripts/rocprof_summary.py gpurun_out/prof_r02c_$1x$2 gpurun_out/prof_r02c_$1x$2_summary.txt; echo "== $1 x $2"; head -5 gpurun_out/prof_r02c_$1x$2_summary.txt | cut -c1-150
+done
