@@ -86,3 +86,27 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
     big.run(UPDATE_DELTA, pbig, 4)
     big.sync()
     assert big.last_kernel_family() == "compact"
+
+
+def test_tick_groups_interleaved_with_the_reference_schedule_and_changing_counts():
+    """run() on all four cascades, then the reference's own schedule (update + one cascade per frame, one left for the flush), then run()
+    on the first two cascades only, then a zero-frame run: the same calls with tick groups off give the same bits everywhere"""
+    n, ids = 256, [0, 1, 2, 3]
+
+    def drive(tick_groups):
+        gen, p = make(n, ids, tick_groups)
+        gen.run(UPDATE_DELTA, p, 7)
+        gen.update(UPDATE_DELTA, p)
+        for _ in range(3):
+            gen._process(0.0)                      # cascade 0 stays armed: flushed by the first tick of the next run
+        gen.run(UPDATE_DELTA, p[:2], 6)            # fewer cascades than the context holds
+        gen.run(UPDATE_DELTA, p, 0)                # nothing
+        gen.run(UPDATE_DELTA, p, 9)
+        gen.sync()
+        return gen, p
+
+    a, pa = drive(True)
+    b, pb = drive(False)
+    assert a.last_kernel_family() == "tick_groups_compact" and b.last_kernel_family() == "layer_parallel_compact"
+    same_maps(a, b, len(ids))
+    assert [x.time for x in pa] == [y.time for y in pb]
