@@ -90,9 +90,9 @@ typedef struct ow_config {
  * Together with OW_FLAG_KERNELS_LAYER_PARALLEL: the layer-parallel kernels on the compact intermediate (map_size >= 256). */
 #define OW_FLAG_KERNELS_COMPACT 8u
 /* ow_run on a small batch (the layer-parallel compact family) normally goes out in tick groups: one launch does pass 2 of up to
- * four consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
+ * four (256^2 x <= 4: eight) consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
  * (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled by
- * four.  Results are bit-identical; this flag keeps ow_run on one pair of launches per tick (tests, measurements). */
+ * several.  Results are bit-identical; this flag keeps ow_run on one pair of launches per tick (tests, measurements). */
 #define OW_FLAG_NO_TICK_GROUPS 16u
 
 typedef struct ow_context ow_context;
@@ -244,7 +244,7 @@ ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_a
  * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c), 4 = layer-parallel on the compact intermediate (k_pass1c_lp /
  * k_pass2c_lp), 5 = that family launched in tick groups by ow_run (k_tick_group_c_lp); 0 before the first launch. */
 int32_t ow_last_kernel_family(const ow_context *ctx);
-/* How many consecutive ticks ow_run puts into one launch for a small batch (tick groups, see OW_FLAG_NO_TICK_GROUPS): 1..4, limited
+/* How many consecutive ticks ow_run puts into one launch for a small batch (tick groups, see OW_FLAG_NO_TICK_GROUPS): 1..8, limited
  * by the scratch memory the double-buffered intermediates take; 0 when this context never uses tick groups. */
 int32_t ow_tick_group_depth(const ow_context *ctx);
 /* Number of cascades the most recent pair of launches processed (the runtime may split a tick into several pairs). */
