@@ -541,6 +541,15 @@ struct TickPlan {
     static constexpr int upper(int slots) { return slots * (GPS / 2) / Q; }      // blocks of layer 1 (upper half rows)
     static constexpr int row0(int slots) { return (slots * 3 + Q - 1) / Q; }     // blocks of the three row-0 transforms
     static constexpr int items_1(int slots) { return 2 * full(slots) + upper(slots) + row0(slots); }
+    // the other pass-1 item form (TickGroupArgs::p1_compact): k_pass1c's -- an 8-row group does all its layers and, for the group
+    // that holds texel row 0, the three extra transforms; Q groups side by side per block, all in the same half of the rows
+    // ((GPS / 2) % Q == 0), so that "skip layer 1 below N/2" stays block-uniform
+    static constexpr int items_1_compact(int slots) { return full(slots); }
+    static OW_HD void decode_compact(int item, int sub, int &slot, int &row0) {
+        const int group = item * Q + sub;
+        slot = group / GPS;
+        row0 = (group % GPS) * kWgRows;
+    }
     static constexpr int items_2(int slots) { return slots * (N / plan_lp_rows(N)); }
     // sub-item `sub` (0..Q-1) of pass-1 item `item`: which (layer / row-0 transform L, launch slot, first row); false = this
     // sub-block has nothing to do (only in the last row-0 item)
@@ -577,6 +586,7 @@ struct TickGroupArgs {
     int32_t tbase2[kMaxTickGroup];   // first scratch slot of each pass-2 tick
     int32_t tbase1[kMaxTickGroup];   // ... of each pass-1 tick
     int32_t slots, n2, n1, d2, d1;
+    int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };
 // fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch
 constexpr int32_t kFaultRowSync = 1;

@@ -106,7 +106,7 @@ template <int N, bool F32>
 static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s) {
     using TP = TickPlan<N>;
     g.n2 = g.d2 > 0 ? TP::items_2(g.slots) : 0;
-    g.n1 = TP::items_1(g.slots);
+    g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;
     if (blocks < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_tick_group_c_lp<N, F32>), dim3(blocks), dim3(plan_lp_threads(N)), 0, s, buf, args, g);

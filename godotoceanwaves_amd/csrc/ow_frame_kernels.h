@@ -468,51 +468,32 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2(DeviceBuffers b
 // ow_device.h and tests/test_compact_math.py for the algebra.  Same structure as k_pass1 / k_pass2 otherwise.
 // ===================================================================================================
 // STAMPS (tools/kbench only): per-wave cycle stamps at the phase boundaries, written to `stamps`
-template <int N, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault, bool STAMPS = false>
-__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
-    unsigned long long ts[STAMPS ? 16 : 1] = {0};
-    auto stamp = [&](int k, float keep) {
-        if constexpr (STAMPS) {
-            asm volatile("" ::"v"(keep));
-            ts[k] = __builtin_readcyclecounter();
-        }
-    };
-    stamp(0, 0.0f);
+// The compact pass 1 of ONE item = 8 consecutive rows row0 .. row0 + 7 of launch slot `tslot` (scratch) / cascade cf.cascade,
+// all layers, as a function of the lane index tau (0 .. 8 * N/16 - 1) inside the item: shared by k_pass1c (one item per block) and
+// by the tick-group kernel (k_tick_group_c_lp: items of several ticks, several side by side in one block).  issued() is called
+// right after the item's global loads have gone out (the stand-alone kernel commits its twiddle prefetch there); the block barriers
+// inside are block-wide: every item of a block must come from the same half of the rows (same layer sequence).
+template <int N, int AUX_T, int AUX_H, class Issued, class Stamper>
+__device__ __forceinline__ void pass1c_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int tau, cplx *tw_lds,
+                                            cplx *rows_lds, RowSync<N> &rs, Issued issued, Stamper stamp) {
     constexpr int Tn = plan_T(N), P = kP, LC = Pass1<N>::kCompactLayers;
-    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
-    const int tau = threadIdx.x;
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
-    RowSync<N> rs;
-    rs.attach(sync_flags, rw, (tau / 64) & 1);
-    rs.watch(buf.status, args.c[0].fault);
-    init_row_sync<N>(sync_flags, kWgRows);
-
-    int slot, row0;
-    p1_block_to_rows<N>(slot, row0);
-    const CascadeFrame cf = args.c[slot];
-    fetch_arguments(buf, cf);
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
-    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
-    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
 
     cplx h[P];
     {
-        TwPrefetch<N> twp;
-        tw_fetch<N>(twp, buf.tw);
         cplx a[P], b[P];
         float om[P];
         Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
-        tw_commit<N>(twp, tw_lds);
-        Pass1<N>::modulate(h, a, b, om, cf.time);
+        issued();
+        Pass1<N>::modulate(h, a, b, om, time);
     }
     stamp(1, h[0].x);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
@@ -547,7 +528,7 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
         }
     }
 
-    // rows below N/2 skip layer 1: hz of row N - y is the conjugate of row y's (block-uniform: a block's 8 rows lie in one half)
+    // rows below N/2 skip layer 1: hz of row N - y is the conjugate of row y's (block-uniform: a block's rows lie in one half)
     const bool lower = row0 < N / 2;
 #pragma unroll
     for (int L = 0; L < LC; ++L) {
@@ -577,6 +558,37 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
         if (L == LC - 1) Pass1<N>::template stage_store<AUX_T>(tau, L, row0, rows_lds, T_c);
         stamp(4 + 3 * L, d[0].x);
     }
+}
+
+template <int N, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault, bool STAMPS = false>
+__global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(DeviceBuffers buf, FrameArgs args, Stamp *stamps = nullptr) {
+    unsigned long long ts[STAMPS ? 16 : 1] = {0};
+    auto stamp = [&](int k, float keep) {
+        if constexpr (STAMPS) {
+            asm volatile("" ::"v"(keep));
+            ts[k] = __builtin_readcyclecounter();
+        }
+    };
+    stamp(0, 0.0f);
+    constexpr int Tn = plan_T(N);
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, tau / Tn, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
+    init_row_sync<N>(sync_flags, kWgRows);
+
+    int slot, row0;
+    p1_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    pass1c_item<N, AUX_T, AUX_H>(buf, cf, cf.time, slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, stamp);
     if constexpr (STAMPS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[14] = __builtin_readcyclecounter();
@@ -1215,7 +1227,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
 // (t mod 2D) * count ...), so pass 1 writes where pass 2 of the launch before last read.  Per texel the arithmetic and its order are
 // those of the one-launch-per-pass kernels: results are bit-identical (tests/test_tick_groups.py).
 // Blocks [0, n2) are pass-2 items (each loops over d2 ticks), blocks [n2, n2 + d1 * n1) pass-1 items of d1 ticks (TickPlan: Q
-// side-by-side 8-row items per block, all of the same layer); d2 or d1 may be 0 (the two ends of a run).
+// side-by-side 8-row items per block -- all of the same layer in the layer-parallel form, each doing all its layers in k_pass1c's
+// form, g.p1_compact, which the runtime picks for all but the smallest ticks); d2 or d1 may be 0 (the two ends of a run).
 // ===================================================================================================
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
@@ -1248,10 +1261,20 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
         }
         return;
     }
-    // ---- pass 1: tick j of the later group, Q items of one layer side by side ----
+    // ---- pass 1: tick j of the later group ----
     const int b1 = (int)blockIdx.x - g.n2, j = b1 / g.n1, item = b1 % g.n1;
     const int tau = threadIdx.x;
     const int sub = __builtin_amdgcn_readfirstlane(tau / SUB), tau_sub = tau % SUB;
+    if (g.p1_compact) {  // (launch-uniform) Q 8-row items side by side, each doing all its layers (k_pass1c's body): no redundant modulation
+        int slot, row0;
+        TP::decode_compact(item, sub, slot, row0);
+        const CascadeFrame cf = args.c[slot];
+        fetch_arguments(buf, cf);
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[j][slot], g.tbase1[j] + slot, row0, tau_sub, tw_lds,
+                                                 rows_lds + sub * kWgRows * plan_region_cplx(N), rs, [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
+        return;
+    }
+    // Q items of one layer side by side (the layer-parallel form)
     int L, slot, row0;
     const bool active = TP::decode(item, sub, g.slots, L, slot, row0);
     // (an idle sub-block of a row-0 item still takes part in the table's block barrier; the row-0 path has no other block barrier,

@@ -67,6 +67,7 @@ struct ow_context {
     uint32_t inject_fault = 0;  // ow_debug_inject_fault: applied to the next batch only
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
+    int group_p1_form = -1;
     int group_max_count = 0, group_depth = 0;
     // timing: a pool of events so that timed ticks stay enqueued back to back
     bool timing = false;
@@ -128,6 +129,9 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     // four ticks per group; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick) -- deeper groups pay only there
     const size_t cap = per_tick <= ((size_t)8 << 20) ? ow::kMaxTickGroup : 4;
     c->group_depth = (int)std::min<size_t>(cap, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
+    // measurement knob (scripts/group_p1_body.py): force one pass-1 item form in the tick groups; -1 = the runtime's own choice
+    c->group_p1_form = -1;
+    if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
 }
 int scratch_slots(const ow_context *c) { return std::max(std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count); }
 
@@ -536,6 +540,11 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.slots = count;
+    // pass-1 items: k_pass1c's form (8 rows, all layers from one load + modulation) for maps of 512^2 up and from 384 Ki texels per
+    // tick on, the layer-parallel form (more, smaller items; the spectrum is modulated once per layer) below -- measured, MI355X, us
+    // per tick lp / compact: 256^2 x 1 4.40 / 4.50, x 4 5.02 / 5.05, x 5 6.01 / 6.28, x 6 7.06 / 6.70, x 8 9.55 / 7.77;
+    // 512^2 x 1 7.25 / 7.04, x 2 10.1 / 8.5, x 4 19.4 / 15.2, x 6 31.4 / 28.1; 1024^2 x 1 19.0 / 15.8   (scripts/group_p1_body.py)
+    ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
     // pass 1 of group 0
     ga.d2 = 0;
     ga.d1 = group_size(0);

@@ -92,7 +92,9 @@ typedef struct ow_config {
 /* ow_run on a small batch (the layer-parallel compact family) normally goes out in tick groups: one launch does pass 2 of up to
  * four (256^2 x <= 4: eight) consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
  * (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled by
- * several.  Results are bit-identical; this flag keeps ow_run on one pair of launches per tick (tests, measurements). */
+ * several.  Results are bit-identical; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
+ * (Measurement knob, read by ow_create: the environment variable OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" forces one of the two forms of
+ * the groups' pass-1 work items; unset, the runtime picks by batch size.  Results do not depend on it.) */
 #define OW_FLAG_NO_TICK_GROUPS 16u
 
 typedef struct ow_context ow_context;

@@ -331,7 +331,32 @@ static int tick_items(int slots, int *out) {
     return cnt;
 }
 
+// the same for the k_pass1c-shaped items (TickGroupArgs::p1_compact): 3 ints per entry = (block, slot, row0)
+template <int N>
+static int tick_items_compact(int slots, int *out) {
+    using TP = TickPlan<N>;
+    int cnt = 0;
+    for (int item = 0; item < TP::items_1_compact(slots); ++item)
+        for (int sub = 0; sub < TP::Q; ++sub) {
+            int slot, row0;
+            TP::decode_compact(item, sub, slot, row0);
+            out[3 * cnt] = item;
+            out[3 * cnt + 1] = slot;
+            out[3 * cnt + 2] = row0;
+            ++cnt;
+        }
+    return cnt;
+}
+
 extern "C" {
+int emul_tick_items_compact(int n, int slots, int *out) {
+    switch (n) {
+        case 256: return tick_items_compact<256>(slots, out);
+        case 512: return tick_items_compact<512>(slots, out);
+        case 1024: return tick_items_compact<1024>(slots, out);
+    }
+    return -1;
+}
 int emul_tick_items(int n, int slots, int *out) {
     switch (n) {
         case 256: return tick_items<256>(slots, out);

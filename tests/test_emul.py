@@ -134,3 +134,12 @@ def test_tick_group_items_cover_every_row_group_exactly_once(emul, n, slots):
     assert got == sorted(want)
     rows_per_item = max(1, 128 // (n // 16))
     assert emul.emul_tick_items_2(n, slots) == slots * n // rows_per_item
+    # the k_pass1c-shaped items: every 8-row group exactly once, and the groups that share a block lie in the same half of the rows
+    # (the block barriers of the layer loop, and "skip layer 1 below N/2", are block-uniform)
+    emul.emul_tick_items_compact.argtypes = emul.emul_tick_items.argtypes
+    cnt = emul.emul_tick_items_compact(n, slots, out)
+    items = out[:cnt]
+    assert sorted(map(tuple, items[:, 1:].tolist())) == sorted((s_, 8 * g) for s_ in range(slots) for g in range(n // 8))
+    for block in np.unique(items[:, 0]):
+        rows = items[items[:, 0] == block]
+        assert len(set(rows[:, 1].tolist())) == 1 and len(set((rows[:, 2] >= n // 2).tolist())) == 1

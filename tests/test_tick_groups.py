@@ -29,9 +29,16 @@ def same_maps(a, b, count):
         assert np.array_equal(na.view(np.uint16), nb.view(np.uint16)), i
 
 
+@pytest.mark.parametrize("p1_form", [None, "lp", "compact"])
 @pytest.mark.parametrize("n,ids", [(256, [0, 1, 2, 3]), (256, [0, 1, 2, 3, 4, 5, 6, 7]), (512, [2]), (512, [0, 1, 2, 3]), (1024, [1])])
 @pytest.mark.parametrize("frames", [2, 3, 4, 17, 40])
-def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames):
+def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, monkeypatch):
+    """p1_form: the runtime picks the pass-1 item form by batch size (layer-parallel items for 256^2 maps below 384 Ki texels per tick,
+    k_pass1c-shaped 8-row items otherwise); both forms are held to the same bits at every size (OW_DEBUG_TICK_GROUP_P1, read by ow_create)."""
+    if p1_form:
+        monkeypatch.setenv("OW_DEBUG_TICK_GROUP_P1", p1_form)
+    else:
+        monkeypatch.delenv("OW_DEBUG_TICK_GROUP_P1", raising=False)
     a, pa = make(n, ids, True)
     b, pb = make(n, ids, False)
     a.run(UPDATE_DELTA, pa, frames)
