@@ -44,6 +44,7 @@ CONTRACT_BYTES = (48, 56)
 #  the memory-side traffic within 1-2 % of these: profiles/pmc_traffic.json)
 FAMILY_BYTES = {"standard": (44, 52), "layer_parallel": (44, 52), "compact": (32, 40), "layer_parallel_compact": (32, 40)}
 SUFFIX = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}
+MERGED_KERNEL = {"tick_groups_compact": "k_tick_group_c_lp", "tick_pairs_compact": "k_tick_pair_c"}  # ow_run's launches merged across ticks
 SWEEP = [(256, 4), (1024, 1), (1024, 8), (2048, 4), (1024, 4)]  # BASELINE.json configs C2, C3', C4 (per node), C5, C3 (headline last)
 
 
@@ -207,8 +208,16 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     # ---- per-kernel durations, in situ: during `probe` further ticks every launch carries start/stop HIP events bound
     #      to its own dispatch packet on the generator's stream (hipExtLaunchKernel): begin -> end of the kernel itself,
     #      the quantity a rocprofv3 kernel trace reports ----
-    gen.timing(True)
     probe = max(50, min(400, args.steps))
+    merged = launch_mode in MERGED_KERNEL
+    gl_ms = gl_n = 0
+    if merged:  # ow_run's merged launches (tick groups / tick pairs), each timed on its own
+        gen.timing(2)
+        gen.run(UPDATE_DELTA, params, probe)
+        gen.sync()
+        gl_ms, gl_n = gen.timing_read_launches()
+        gen.timing(False)
+    gen.timing(True)
     gen.run(UPDATE_DELTA, params, probe)
     gen.sync()
     p1_ms, p2_ms, launches = gen.timing_read()
@@ -232,18 +241,27 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     dom_ms = max(p1_ms, p2_ms)
     dom_bpt, dom_contract = (k1, CONTRACT_BYTES[0]) if first else (k2, CONTRACT_BYTES[1])
     gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    grouped = launch_mode == "tick_groups_compact"
+    grouped = merged
     if grouped:
-        # ow_run launched the timed ticks in groups (k_tick_group_c_lp: pass 2 of 4 ticks + pass 1 of the next 4 per launch, back to
-        # back): the kernel that dominates the timed region is that one, its launch lasts GROUP ticks of the timed region, and it
-        # moves both passes' bytes of GROUP (= ow_tick_group_depth) ticks.  (p1 / p2 below are the one-launch-per-pass kernels of the same tick, probed after.)
+        # ow_run launched the timed ticks merged across ticks -- tick groups (k_tick_group_c_lp: pass 2 of GROUP ticks + pass 1 of the next
+        # GROUP per launch) or tick pairs (k_tick_pair_c: pass 2 of one tick + pass 1 of the next, GROUP = 1): that kernel dominates the
+        # timed region.  Its launches were timed one by one (HIP events on each dispatch, timing mode 2) over `probe` further ticks, of
+        # which the first takes the ordinary path: T = probe - 1 ticks in ceil(T / GROUP) + 1 launches (the first carries pass 1
+        # only, the last pass 2 only).  achieved = all bytes those launches move / the sum of their durations.
+        # (p1 / p2 below are the one-launch-per-pass kernels of the same tick, probed after.)
         GROUP = max(1, group_depth)
-        dom, dom_ms = "k_tick_group_c_lp", elapsed / args.steps * 1e3 * GROUP
-        # (foam is read before the first and written after the last of the GROUP ticks only: 4 B/texel less for each tick in between)
+        dom, dom_ms = MERGED_KERNEL[launch_mode], gl_ms
+        # (foam is read before the first and written after the last of a group's ticks only: 4 B/texel less for each tick in between)
         dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C
         per_launch = C
-    achieved = gbps(dom_bpt * texels, dom_ms)  # (grouped: texels of one tick x bytes of GROUP ticks)
-    contract = gbps(dom_contract * texels, dom_ms)
+        T = probe - 1
+        groups = -(-T // GROUP)
+        total_bytes = ((k1 + k2) * T - 4 * (T - groups)) * n * n * C
+        achieved = gbps(total_bytes, gl_ms * gl_n)
+        contract = gbps(sum(CONTRACT_BYTES) * T * n * n * C, gl_ms * gl_n)
+    else:
+        achieved = gbps(dom_bpt * texels, dom_ms)
+        contract = gbps(dom_contract * texels, dom_ms)
     tick_s = elapsed / args.steps
     tick_bpt = (dom_bpt / max(1, group_depth)) if grouped else (k1 + k2)
     tick_moved = tick_bpt * n * n * C / tick_s / 1e9          # per GPU
@@ -270,8 +288,10 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         "config": {"workload": f"{n}^2 x {C} cascades per GPU, steady-state tick (modulate + 2-D IFFT + unpack/foam), "
                                f"delta=1/50 s, SURVEY 8d cascade table",
                    "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
-                   "launches": f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp); the in-situ kernel "
-                               "durations below are those of the same ticks launched one pass at a time" if launch_mode == "tick_groups_compact"
+                   "launches": (f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp)"
+                                if launch_mode == "tick_groups_compact" else
+                                "tick pairs: pass 2 of tick t and pass 1 of tick t + 1 in one launch (k_tick_pair_c)") +
+                               "; pass1_ms / pass2_ms below are those of the same ticks launched one pass at a time" if grouped
                                else "one pair of launches per batch and tick",
                    "gather": (f"{args.gather}, every {args.gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
                              if (world > 1 and args.gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
@@ -283,7 +303,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "bytes_per_texel": dom_bpt, "bytes_per_launch": int(dom_bpt * texels),
             "bytes_basis": "bytes the launched kernel family must move (bench.py FAMILY_BYTES, DESIGN.md section 3)" +
-                           (f"; one launch = both passes of {max(1, group_depth)} ticks, its duration taken from the timed region (launches back to back)" if grouped else ""),
+                           (f"; one launch = both passes of {max(1, group_depth)} tick(s); achieved = all bytes of the {gl_n} launches timed one by one / the sum of their durations "
+                            "(the first and last launch of a run carry one pass only)" if grouped else ""),
             "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBPS, 4), "copy_ceiling": COPY_CEILING_GBPS,
             # SURVEY 8d's contract bytes (four-layer FP32 intermediate, 104 B/texel per map) over the same duration: a
             # figure of merit against a design that moves more, NOT a bandwidth (it can exceed the copy ceiling)

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ow_jonswap_peak_angular_frequency": (C.c_double, [C.c_double, C.c_double]),
     "ow_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "ow_timing_read": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_int32), C.c_int32]),
+    "ow_timing_read_launches": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_int32), C.c_int32]),
     "ow_probe_kernel_times": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_float), _P(C.c_float), _P(C.c_int32)]),
     "ow_last_error": (C.c_char_p, []),
     "ow_abi_version": (C.c_int32, []),

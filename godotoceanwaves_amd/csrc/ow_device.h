@@ -586,6 +586,7 @@ struct TickGroupArgs {
     int32_t tbase2[kMaxTickGroup];   // first scratch slot of each pass-2 tick
     int32_t tbase1[kMaxTickGroup];   // ... of each pass-1 tick
     int32_t slots, n2, n1, d2, d1;
+    int32_t pair_compact;            // k_tick_pair_c instead: the compact family's bodies, one tick of each pass (d2, d1 <= 1)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };
 // fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch

@@ -103,20 +103,28 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
 
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----
 template <int N, bool F32>
-static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s) {
+static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     using TP = TickPlan<N>;
+    if (g.pair_compact) {  // tick pairs on the compact family: k_pass2c's blocks of one tick, k_pass1c's of the next
+        if (g.d2 > 1 || g.d1 > 1) return hipErrorInvalidValue;
+        g.n2 = g.d2 * g.slots * (N / kWgRows);
+        g.n1 = g.d1 * g.slots * (N / kWgRows);
+        if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
+        launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+        return hipGetLastError();
+    }
     g.n2 = g.d2 > 0 ? TP::items_2(g.slots) : 0;
     g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;
     if (blocks < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_tick_group_c_lp<N, F32>), dim3(blocks), dim3(plan_lp_threads(N)), 0, s, buf, args, g);
+    launch(k_tick_group_c_lp<N, F32>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g);
     return hipGetLastError();
 }
 bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
-hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s) {
+hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
 #define OW_GROUP(NN) \
-    case NN: return buf.f32 ? launch_group_n<NN, true>(args, g, buf, s) : launch_group_n<NN, false>(args, g, buf, s);
+    case NN: return buf.f32 ? launch_group_n<NN, true>(args, g, buf, s, lt) : launch_group_n<NN, false>(args, g, buf, s, lt);
     switch (n) {
         OW_GROUP(256)
         OW_GROUP(512)

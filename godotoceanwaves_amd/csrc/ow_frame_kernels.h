@@ -219,9 +219,9 @@ __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cp
 //    read the same h0 / omega lines (Pass1::load_modulate) and the XCD's L2 fetches them from HBM once.
 // SUB > 1: the 8-row unit is shared by SUB consecutive blocks of 8 / SUB rows each (split plan with smaller blocks)
 template <int N, int SUB = 1>
-__device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
+__device__ __forceinline__ void p1_index_to_rows(int index, int &slot, int &row0) {
     constexpr int G = N / 16;  // 16-row groups per cascade; 2*G blocks per cascade
-    const int b = blockIdx.x / SUB, x = b & 7, i = b >> 3;
+    const int b = index / SUB, x = b & 7, i = b >> 3;
     if constexpr (G >= 16) {
         constexpr int PER = G / 4;  // blocks per XCD per cascade: G/16 mirror pairs x 2 groups x 2 halves
         slot = i / PER;
@@ -234,7 +234,11 @@ __device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
         slot = grow / N;
         row0 = grow % N;
     }
-    if constexpr (SUB > 1) row0 += (int)(blockIdx.x % SUB) * (kWgRows / SUB);
+    if constexpr (SUB > 1) row0 += (index % SUB) * (kWgRows / SUB);
+}
+template <int N, int SUB = 1>
+__device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
+    p1_index_to_rows<N, SUB>((int)blockIdx.x, slot, row0);
 }
 template <int N>
 __device__ __forceinline__ void p2_block_to_rows(int &slot, int &row0) {
@@ -603,31 +607,21 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
     }
 }
 
-template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
-__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers buf, FrameArgs args) {
+// The compact pass 2 of ONE item = 8 consecutive columns row0 .. row0 + 7 of launch slot `tslot` (scratch) / cascade cf.cascade, as
+// a function of the lane index tau inside the item: shared by k_pass2c and the compact tick-group kernel (k_tick_group_c, where a
+// block walks through several ticks of its columns).  foam_pk: the lane's 16 FP16 foam values; foam_io & 1: load them from the
+// foam plane first, & 2: store them back at the end (the group kernel carries them in registers from tick to tick).
+template <int N, bool F32, int AUX_T, int AUX_O, class Issued>
+__device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds, cplx *rows_lds,
+                                            RowSync<N> &rs, Issued issued, uint32_t (&foam_pk)[kP / 2], int foam_io = 3) {
     constexpr int Tn = plan_T(N), P = kP;
-    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
-    const int tau = threadIdx.x;
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
-    RowSync<N> rs;
-    rs.attach(sync_flags, rw, (tau / 64) & 1);
-    rs.watch(buf.status, args.c[0].fault);
-    init_row_sync<N>(sync_flags, kWgRows);
-
-    int slot, row0;
-    p2_block_to_rows<N>(slot, row0);
-    const CascadeFrame cf = args.c[slot];
-    fetch_arguments(buf, cf);
     const int xp = row0 + rw;
-    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
-    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
-    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
     const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
@@ -641,11 +635,9 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     {
         cplx f2[P];
         OW_SCHED_FENCE();
-        TwPrefetch<N> twp;
-        tw_fetch<N>(twp, buf.tw);
         Pass2<N>::template load_c1<AUX_T>(f2, t, xp, dky, T_c);
         const cplx r2 = side_row(2);
-        tw_commit<N>(twp, tw_lds);
+        issued();
         Pass2<N>::put_row0(f2, t, r2);
         row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
@@ -681,14 +673,37 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
         const int tq = opaque(t);
         Pass2<N>::template load_layer<AUX_T>(f3, tq, xp, 2, T_c);
         Pass2<N>::put_row0(f3, tq, side_row(3));
-        uint32_t foam_pk[P / 2];
-        Pass2<N>::load_foam(foam_pk, tq, xp, foam_c);
+        if (foam_io & 1) Pass2<N>::load_foam(foam_pk, tq, xp, foam_c);
         row_ifft<N>(f3, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         const int tr = opaque(t);
         Pass2<N>::template after_f3<F32, AUX_O>(f3, dhx_dx, c2, gx_pk, foam_pk, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
-        Pass2<N>::store_foam(foam_pk, tr, xp, foam_c);
+        if (foam_io & 2) Pass2<N>::store_foam(foam_pk, tr, xp, foam_c);
     }
+}
+
+template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers buf, FrameArgs args) {
+    constexpr int Tn = plan_T(N);
+    static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    RowSync<N> rs;
+    rs.attach(sync_flags, tau / Tn, (tau / 64) & 1);
+    rs.watch(buf.status, args.c[0].fault);
+    init_row_sync<N>(sync_flags, kWgRows);
+
+    int slot, row0;
+    p2_block_to_rows<N>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    uint32_t foam_pk[kP / 2];
+    pass2c_item<N, F32, AUX_T, AUX_O>(buf, cf, slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
 }
 
 // ===================================================================================================
@@ -1286,6 +1301,56 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
                                        rs, [&] { tw_commit<N>(twp, tw_lds); }, ws);
     } else {
         tw_commit<N>(twp, tw_lds);
+    }
+}
+
+// TICK PAIRS on the compact family (ow_run on the batches that family serves, up to 4 Mi texels per tick): ONE launch per tick does
+// pass 2 of tick t (k_pass2c's blocks: 8 columns) and pass 1 of tick t + 1 (k_pass1c's blocks: 8 rows) -- independent work; the
+// scratch intermediate is two ticks deep (g.tbase2[0] / g.tbase1[0]).  Chunks of 8 blocks (one block per XCD, so both block -> rows
+// maps keep their XCD placement) alternate between the two passes: a CU holds blocks of both, pass 1's exposed transform time
+// overlaps pass 2's memory time, and the launch gap and the tail of one kernel per tick are gone.  Same item bodies as k_pass1c /
+// k_pass2c: results are bit-identical to one launch pair per tick.  g.d2 / g.d1 in {0, 1}: the two ends of a run have one pass only.
+// (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 29.0 / 38.6, x 3 42.5 / 50.7, x 4 54.6 / 57.0, 512^2 x 8 28.8 / 34.8.
+//  Deeper groups -- a block walking through 2 or 4 ticks of its columns as in k_tick_group_c_lp -- gain nothing more here and lose
+//  once the deeper scratch leaves the Infinity Cache; profiles/r02_tick_pairs_compact.txt.)
+template <int N, bool F32>
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
+    static_assert(!plan_row_spans_waves(N), "N <= 1024");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    RowSync<N> rs;
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
+    // g.n2 pass-2 blocks and g.n1 pass-1 blocks (multiples of 8, either may be 0): alternate in chunks of 8 while both last
+    int index = blockIdx.x;
+    bool first;  // is this a pass-1 block?
+    {
+        const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
+        if (index < both) {
+            first = chunk & 1;
+            index = ((chunk >> 1) << 3) + (index & 7);
+        } else {
+            first = g.n2 < g.n1;
+            index -= both / 2;
+        }
+    }
+    int slot, row0;
+    if (!first) {
+        constexpr int BPC = N / kWgRows;
+        slot = index / BPC;
+        row0 = (index % BPC) * kWgRows;
+    } else {
+        p1_index_to_rows<N>(index, slot, row0);
+    }
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    if (!first) {
+        uint32_t foam_pk[kP / 2];
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
+    } else {
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][slot], g.tbase1[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
+                                                 [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
     }
 }
 

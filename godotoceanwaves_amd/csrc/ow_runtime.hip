@@ -69,12 +69,16 @@ struct ow_context {
     // into one group; the scratch buffers hold 2 * depth * count cascades then
     int group_p1_form = -1;
     int group_max_count = 0, group_depth = 0;
+    // ow_run's tick pairs on the compact family (k_tick_pair_c): the largest cascade count they serve; scratch two ticks deep
+    int pair_max_count = 0;
+    int last_group_depth = 0;  // ticks per launch of the most recent ow_run that went out in groups / pairs
     // timing: a pool of events so that timed ticks stay enqueued back to back
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 per pass (ow_run stays on one launch per pass), 2 as launched (tick groups / pairs stay on, timed per launch)
+    std::vector<char> ev_single;  // per 4-event record: 1 = one launch (events 0, 1 only): a tick group / pair
     std::vector<hipEvent_t> ev;  // 4 per timed batch: start/stop of the pass-1 dispatch, start/stop of the pass-2 dispatch
     size_t ev_used = 0;
-    double t1_ms = 0, t2_ms = 0;
-    int t_launches = 0;
+    double t1_ms = 0, t2_ms = 0, tg_ms = 0;
+    int t_launches = 0, tg_launches = 0;
     int slot_of[OW_MAX_CASCADES];  // launch slot of each cascade in the most recent batch, -1 if it was not in it
     // last batch that was launched (for ow_probe_kernel_times)
     ow::FrameArgs last_args{};
@@ -117,9 +121,15 @@ int batch_size(const ow_context *c, int count) {
 // (with 1 GiB instead -- depth 4 up to 1024^2 x 2 -- nothing changes where it matters: 1024^2 x 2 39.4 vs 39.4 us on k_pass1c + k_pass2c,
 // x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
 constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
+// Ticks of the compact family up to kPairTexels go out as tick pairs (k_tick_pair_c: pass 2 of tick t and pass 1 of tick t + 1 in one
+// launch), scratch two ticks deep: at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds
+// next to the spectra; beyond (1024^2 x 5, x 6) the pairs lose to one launch per pass (measured: profiles/r02_tick_pairs_compact.txt).
+constexpr size_t kPairTexels = (size_t)4 << 20;
 void plan_tick_groups(ow_context *c, uint32_t flags) {
-    c->group_max_count = c->group_depth = 0;
-    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n) || (c->kernel_mode != 0 && c->kernel_mode != 4)) return;
+    c->group_max_count = c->group_depth = c->pair_max_count = 0;
+    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
+    for (int count = 1; count <= c->cascades; ++count)
+        if (ow::kernel_family(c->n, count, c->kernel_mode) == 3 && (size_t)count * c->n * c->n <= kPairTexels) c->pair_max_count = count;
     int best = 0;
     for (int count = 1; count <= c->cascades; ++count)
         if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;
@@ -133,7 +143,9 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_p1_form = -1;
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
 }
-int scratch_slots(const ow_context *c) { return std::max(std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count); }
+int scratch_slots(const ow_context *c) {
+    return std::max({std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count, 2 * c->pair_max_count});
+}
 
 constexpr size_t kMaxTimedBatches = 4096;
 
@@ -143,6 +155,11 @@ ow_status collect_timing(ow_context *c) {
     for (size_t i = 0; i + 4 <= c->ev_used; i += 4) {
         float a = 0, b = 0;
         OW_HIP(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
+        if (i / 4 < c->ev_single.size() && c->ev_single[i / 4]) {
+            c->tg_ms += a;
+            c->tg_launches += 1;
+            continue;
+        }
         OW_HIP(hipEventElapsedTime(&b, c->ev[i + 2], c->ev[i + 3]));
         c->t1_ms += a;
         c->t2_ms += b;
@@ -152,7 +169,7 @@ ow_status collect_timing(ow_context *c) {
     return OW_OK;
 }
 
-ow_status next_events(ow_context *c, hipEvent_t **out) {
+ow_status next_events(ow_context *c, hipEvent_t **out, bool single = false) {
     if (c->ev_used + 4 > 4 * kMaxTimedBatches) {
         ow_status st = collect_timing(c);
         if (st != OW_OK) return st;
@@ -163,6 +180,8 @@ ow_status next_events(ow_context *c, hipEvent_t **out) {
         c->ev.push_back(e);
     }
     *out = &c->ev[c->ev_used];
+    if (c->ev_single.size() < c->ev_used / 4 + 1) c->ev_single.resize(c->ev_used / 4 + 1);
+    c->ev_single[c->ev_used / 4] = single ? 1 : 0;
     c->ev_used += 4;
     return OW_OK;
 }
@@ -507,15 +526,19 @@ ow_status ow_debug_inject_fault(ow_context *c, uint32_t fault_bits) {
 
 namespace {
 
-// Can the remaining ticks of ow_run go out as tick groups?  Only a batch of the layer-parallel compact family, with nothing left
+// Can the remaining ticks of ow_run go out as tick groups / tick pairs?  Only a batch of the layer-parallel compact family (groups)
+// or a batch of the compact family of at most kPairTexels (pairs), with nothing left
 // armed, no spectrum to regenerate, no fault to inject, no per-launch timing requested, and records that pass enqueue()'s checks.
-bool tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
-    if (c->group_max_count == 0 || count > c->group_max_count || c->timing || c->inject_fault || c->pass_num_cascades_remaining != 0) return false;
-    if (ow::kernel_family(c->n, count, c->kernel_mode) != 4) return false;
+// returns the ticks per launch: 0 = not usable, group_depth for the tick groups, 1 for the compact family's tick pairs
+int tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
+    if (c->timing == 1 || c->inject_fault || c->pass_num_cascades_remaining != 0) return 0;
+    const int fam = ow::kernel_family(c->n, count, c->kernel_mode);
+    const bool groups = fam == 4 && count <= c->group_max_count, pairs = fam == 3 && count <= c->pair_max_count;
+    if (!groups && !pairs) return 0;
     for (int i = 0; i < count; ++i)
         if (params[i].should_generate_spectrum || !finite_record(params[i]) || !(params[i].tile_length[0] > 0.0f) || !(params[i].tile_length[1] > 0.0f))
-            return false;  // (the ordinary path regenerates / reports)
-    return true;
+            return 0;  // (the ordinary path regenerates / reports)
+    return groups ? c->group_depth : 1;
 }
 
 // one more ow_update_all() worth of arithmetic on the records (wave_generator.gd:101-106); time_out[i] = FP32 time of launch
@@ -533,13 +556,14 @@ void advance_tick(double delta, ow_cascade_params *params, int count, float *tim
 
 // `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
 //   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
-ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
-    const int D = c->group_depth, groups = (ticks + D - 1) / D;
+ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D) {
+    const int groups = (ticks + D - 1) / D;
     auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
     auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.slots = count;
+    ga.pair_compact = ow::kernel_family(c->n, count, c->kernel_mode) == 3;  // (then D = 1)
     // pass-1 items: k_pass1c's form (8 rows, all layers from one load + modulation) for maps of 512^2 up and from 384 Ki texels per
     // tick on, the layer-parallel form (more, smaller items; the spectrum is modulated once per layer) below -- measured, MI355X, us
     // per tick lp / compact: 256^2 x 1 4.40 / 4.50, x 4 5.02 / 5.05, x 5 6.01 / 6.28, x 6 7.06 / 6.70, x 8 9.55 / 7.77;
@@ -565,7 +589,16 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
         cf.foam_decay = expf(-(float)p.foam_decay_rate);
         cf.cascade = count - 1 - i;
     }
-    OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream));
+    auto launch = [&]() -> ow_status {
+        hipEvent_t *ev = nullptr;
+        if (c->timing == 2) {
+            ow_status st = next_events(c, &ev, true);
+            if (st != OW_OK) return st;
+        }
+        OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, ow::LaunchTiming{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}));
+        return OW_OK;
+    };
+    if (ow_status st = launch(); st != OW_OK) return st;
     for (int g = 0; g < groups; ++g) {
         ga.d2 = group_size(g);
         for (int j = 0; j < ga.d2; ++j) ga.tbase2[j] = slot_of_tick(g * D + j);
@@ -574,7 +607,7 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
             advance_tick(delta, params, count, ga.time1[j]);
             ga.tbase1[j] = slot_of_tick((g + 1) * D + j);
         }
-        OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream));
+        if (ow_status st = launch(); st != OW_OK) return st;
     }
     for (int i = 0; i < count; ++i) {
         c->pass_parameters[i] = params[i];
@@ -584,7 +617,8 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
     c->pass_num_cascades_remaining = 0;
     c->last_args = args;
     c->last_count = count;
-    c->last_family = 5;
+    c->last_family = ga.pair_compact ? 6 : 5;
+    c->last_group_depth = D;
     for (int &sl : c->slot_of) sl = -1;  // (no reference-layout intermediate to inspect after such a run)
     return OW_OK;
 }
@@ -602,9 +636,10 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         f = 1;
     }
     // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
-    if (frames - f >= 2 && std::isfinite(delta) && tick_groups_usable(c, params, count)) {
+    const int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
+    if (depth > 0) {
         OW_HIP(hipSetDevice(c->device));
-        ow_status st = run_tick_groups(c, delta, params, count, frames - f);
+        ow_status st = run_tick_groups(c, delta, params, count, frames - f, depth);
         if (st != OW_OK) return st;
         f = frames;
     }
@@ -617,7 +652,10 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
 
 int32_t ow_last_kernel_family(const ow_context *c) { return c ? c->last_family : 0; }
 int32_t ow_last_batch_cascades(const ow_context *c) { return c ? c->last_count : 0; }
-int32_t ow_tick_group_depth(const ow_context *c) { return c ? c->group_depth : 0; }
+int32_t ow_tick_group_depth(const ow_context *c) {
+    if (!c) return 0;
+    return c->last_family >= 5 ? c->last_group_depth : c->group_depth;
+}
 
 int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_cascades_remaining : 0; }
 
@@ -857,7 +895,7 @@ ow_status ow_timing_enable(ow_context *c, int32_t enable) {
         ow_status st = collect_timing(c);
         if (st != OW_OK) return st;
     }
-    c->timing = enable != 0;
+    c->timing = enable == 2 ? 2 : enable != 0;
     return OW_OK;
 }
 
@@ -872,6 +910,19 @@ ow_status ow_timing_read(ow_context *c, float *p1, float *p2, int32_t *launches,
     if (reset) {
         c->t1_ms = c->t2_ms = 0;
         c->t_launches = 0;
+    }
+    return OW_OK;
+}
+
+ow_status ow_timing_read_launches(ow_context *c, float *launch_ms_avg, int32_t *launches, int32_t reset) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    ow_status st = collect_timing(c);
+    if (st != OW_OK) return st;
+    if (launch_ms_avg) *launch_ms_avg = c->tg_launches ? (float)(c->tg_ms / c->tg_launches) : 0.0f;
+    if (launches) *launches = c->tg_launches;
+    if (reset) {
+        c->tg_ms = 0;
+        c->tg_launches = 0;
     }
     return OW_OK;
 }

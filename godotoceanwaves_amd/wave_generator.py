@@ -270,7 +270,8 @@ class WaveGenerator:
         _lib.check(self._lib.ow_get_intermediate(self.context, cascade, out.ctypes.data))
         return out
 
-    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact", 4: "layer_parallel_compact", 5: "tick_groups_compact"}
+    KERNEL_FAMILIES = {0: None, 1: "standard", 2: "layer_parallel", 3: "compact", 4: "layer_parallel_compact", 5: "tick_groups_compact",
+                       6: "tick_pairs_compact"}
 
     def last_kernel_family(self):
         """which kernels the most recent batch ran with: "standard", "layer_parallel", "compact" (None before the first launch)"""
@@ -281,11 +282,14 @@ class WaveGenerator:
         return int(self._lib.ow_last_batch_cascades(self.context))
 
     def tick_group_depth(self):
-        """ticks per launch of run() on a small batch (0: this context never uses tick groups)"""
+        """ticks per launch: of the most recent run() that went out in tick groups / tick pairs, else the depth planned for this
+        context's small batches (0: no tick groups)"""
         return int(self._lib.ow_tick_group_depth(self.context))
 
     def timing(self, enable):
-        _lib.check(self._lib.ow_timing_enable(self.context, 1 if enable else 0))
+        """False / 0: off; True / 1: per pass (run() stays on one launch per pass); 2: as launched (tick groups / pairs stay on and are
+        timed per launch: timing_read_launches)"""
+        _lib.check(self._lib.ow_timing_enable(self.context, 2 if enable == 2 else (1 if enable else 0)))
 
     def probe_kernel_times(self, reps=50):
         """(pass1_ms, pass2_ms, cascades_per_launch): each kernel alone, `reps` back-to-back launches (benchmark probe;
@@ -293,6 +297,12 @@ class WaveGenerator:
         a, b, n = C.c_float(), C.c_float(), C.c_int32()
         _lib.check(self._lib.ow_probe_kernel_times(self.context, reps, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def timing_read_launches(self, reset=True):
+        """(average ms, count) of the tick-group / tick-pair launches timed under timing(2)"""
+        a, n = C.c_float(), C.c_int32()
+        _lib.check(self._lib.ow_timing_read_launches(self.context, C.byref(a), C.byref(n), 1 if reset else 0))
+        return a.value, n.value
 
     def timing_read(self, reset=True):
         a, b, n = C.c_float(), C.c_float(), C.c_int32()

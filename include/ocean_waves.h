@@ -89,10 +89,14 @@ typedef struct ow_config {
  * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them.
  * Together with OW_FLAG_KERNELS_LAYER_PARALLEL: the layer-parallel kernels on the compact intermediate (map_size >= 256). */
 #define OW_FLAG_KERNELS_COMPACT 8u
-/* ow_run on a small batch (the layer-parallel compact family) normally goes out in tick groups: one launch does pass 2 of up to
- * four (256^2 x <= 4: eight) consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
- * (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled by
- * several.  Results are bit-identical; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
+/* ow_run merges launches across ticks where that pays (the first tick of a run always takes the ordinary path):
+ *  - TICK GROUPS, small batches (the layer-parallel compact family): one launch does pass 2 of up to four (256^2 x <= 4: eight)
+ *    consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
+ *    (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled
+ *    by several (k_tick_group_c_lp);
+ *  - TICK PAIRS, batches of the compact family of at most 4 Mi texels per tick (1024^2 x 2 .. 4, 512^2 x 7 ..): one launch per tick
+ *    does pass 2 of tick t and pass 1 of tick t + 1 (k_tick_pair_c).
+ * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
  * (Measurement knob, read by ow_create: the environment variable OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" forces one of the two forms of
  * the groups' pass-1 work items; unset, the runtime picks by batch size.  Results do not depend on it.) */
 #define OW_FLAG_NO_TICK_GROUPS 16u
@@ -238,16 +242,22 @@ double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_
 
 /* Average duration (ms) of the two frame kernels over the launches made since the last reset, in situ: while
  * enabled, every launch carries start/stop hipEvents bound to its own dispatch packet (hipExtLaunchKernel), so the
- * figure is the kernel's begin -> end exactly as a rocprofv3 kernel trace reports it.  Throughput runs keep it off. */
+ * figure is the kernel's begin -> end exactly as a rocprofv3 kernel trace reports it.  Throughput runs keep it off.
+ * enable = 1: per pass -- ow_run stays on one launch per pass while enabled (ow_timing_read);
+ * enable = 2: as launched -- ow_run keeps its tick groups / tick pairs and every such launch is timed (ow_timing_read_launches: average
+ *             duration of those launches; the first and the last launch of a run carry one pass only), other launches as with 1. */
 ow_status ow_timing_enable(ow_context *ctx, int32_t enable);
 ow_status ow_timing_read(ow_context *ctx, float *pass1_ms_avg, float *pass2_ms_avg, int32_t *launches, int32_t reset);
+ow_status ow_timing_read_launches(ow_context *ctx, float *launch_ms_avg, int32_t *launches, int32_t reset);
 
 /* Kernel family the most recent batch was launched with: 1 = standard (k_pass1 / k_pass2), 2 = layer-parallel
  * (k_pass1_lp / k_pass2_lp), 3 = compact intermediate (k_pass1c / k_pass2c), 4 = layer-parallel on the compact intermediate (k_pass1c_lp /
- * k_pass2c_lp), 5 = that family launched in tick groups by ow_run (k_tick_group_c_lp); 0 before the first launch. */
+ * k_pass2c_lp), 5 = that family launched in tick groups by ow_run (k_tick_group_c_lp), 6 = the compact family launched in tick pairs
+ * by ow_run (k_tick_pair_c: pass 2 of one tick and pass 1 of the next in one launch); 0 before the first launch. */
 int32_t ow_last_kernel_family(const ow_context *ctx);
-/* How many consecutive ticks ow_run puts into one launch for a small batch (tick groups, see OW_FLAG_NO_TICK_GROUPS): 1..8, limited
- * by the scratch memory the double-buffered intermediates take; 0 when this context never uses tick groups. */
+/* How many consecutive ticks ow_run puts into one launch (tick groups, see OW_FLAG_NO_TICK_GROUPS): after an ow_run that went out in
+ * tick groups or tick pairs (ow_last_kernel_family 5 / 6) the depth it used -- 1..8 for groups, limited by the scratch memory the
+ * double-buffered intermediates take, 1 for pairs; otherwise the depth planned for this context's small batches (0: no tick groups). */
 int32_t ow_tick_group_depth(const ow_context *ctx);
 /* Number of cascades the most recent pair of launches processed (the runtime may split a tick into several pairs). */
 int32_t ow_last_batch_cascades(const ow_context *ctx);

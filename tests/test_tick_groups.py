@@ -1,4 +1,6 @@
-"""ow_run on a small batch: from the second tick on, pass 2 of tick k and pass 1 of tick k + 1 go out in ONE launch (k_tick_group_c_lp;
+"""ow_run on a batch of the compact family of at most 4 Mi texels per tick goes out in TICK PAIRS (k_tick_pair_c: pass 2 of tick t and pass 1
+of tick t + 1 in one launch, the compact family's own item bodies) -- held to one launch per pass BITWISE below, too.
+ow_run on a small batch: from the second tick on, pass 2 of tick k and pass 1 of tick k + 1 go out in ONE launch (k_tick_group_c_lp;
 the two are independent, the scratch intermediate is double-buffered by tick parity) -- against the same ticks as one pair of
 launches each.  Same lane code in the same order per texel, so the comparison is BITWISE; the golden 1000-frame loop
 (tests/test_golden.py, BASELINE config C2) runs through the tick groups as well and holds them to the oracle's trajectory."""
@@ -57,6 +59,73 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, mon
     same_maps(a, b, len(ids))
 
 
+@pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7])])
+@pytest.mark.parametrize("frames", [2, 3, 4, 9])
+def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
+    a, pa = make(n, ids, True)
+    b, pb = make(n, ids, False)
+    a.run(UPDATE_DELTA, pa, frames)
+    b.run(UPDATE_DELTA, pb, frames)
+    a.sync(); b.sync()
+    assert a.last_kernel_family() == ("tick_pairs_compact" if frames >= 3 else "compact")
+    assert b.last_kernel_family() == "compact"
+    if frames >= 3:
+        assert a.tick_group_depth() == 1
+    same_maps(a, b, len(ids))
+    for x, y in zip(pa, pb):
+        assert x.time == y.time and x.foam_grow_rate == y.foam_grow_rate and x.foam_decay_rate == y.foam_decay_rate
+    # the state carries on seamlessly on either path: the reference's schedule, a run on fewer cascades, another full run
+    for gen, p in ((a, pa), (b, pb)):
+        gen.update(UPDATE_DELTA, p)
+        for _ in range(len(ids) - 1):
+            gen._process(0.0)
+        gen.run(UPDATE_DELTA, p[:2], 5)
+        gen.run(UPDATE_DELTA, p, 6)
+        gen.sync()
+    same_maps(a, b, len(ids))
+    assert [x.time for x in pa] == [y.time for y in pb]
+
+
+def test_tick_pairs_keep_the_debug_channels_and_match_the_oracle():
+    n, ids, frames = 512, [0, 1, 2, 3, 4, 5, 6, 7], 4
+    gen, params = make(n, ids, True, debug=True)
+    og = H.oracle_generator(n, ids)
+    gen.run(UPDATE_DELTA, params, frames)
+    for _ in range(frames):
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() == "tick_pairs_compact"
+    for i in (0, 7):
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
+
+
+def test_timing_as_launched_keeps_the_merged_launches():
+    """timing mode 2: tick groups / tick pairs stay on and every such launch is timed; mode 1 puts ow_run back on one launch per pass"""
+    for n, ids, fam, depth in ((1024, [0, 1], "tick_pairs_compact", 1), (256, [0, 1, 2, 3], "tick_groups_compact", 8)):
+        gen, p = make(n, ids, True)
+        gen.timing(2)
+        gen.run(UPDATE_DELTA, p, 34)
+        gen.sync()
+        ms, launches = gen.timing_read_launches()
+        assert gen.last_kernel_family() == fam and gen.tick_group_depth() == depth
+        assert launches == -(-33 // depth) + 1 and 0.0 < ms < 5.0
+        p1, p2, pairs = gen.timing_read()
+        assert pairs == 1 and p1 > 0 and p2 > 0   # the run's first tick took the ordinary path, timed per pass
+        gen.timing(True)
+        gen.run(UPDATE_DELTA, p, 5)
+        gen.sync()
+        assert gen.last_kernel_family() in ("compact", "layer_parallel_compact")
+        assert gen.timing_read()[2] == 5 and gen.timing_read_launches()[1] == 0
+        gen.timing(False)
+
+
 def test_tick_groups_match_the_oracle_and_keep_the_debug_channels():
     n, ids, frames = 256, [0, 1, 2, 3], 6
     gen, params = make(n, ids, True, debug=True)
@@ -89,7 +158,7 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
     a.sync(); b.sync()
     assert a.last_kernel_family() == "tick_groups_compact"
     same_maps(a, b, len(ids))
-    big, pbig = make(1024, [0, 1], True)
+    big, pbig = make(1024, [0, 1, 2, 3, 4], True)   # 5 Mi texels per tick: beyond the tick pairs as well
     big.run(UPDATE_DELTA, pbig, 4)
     big.sync()
     assert big.last_kernel_family() == "compact"
