@@ -252,10 +252,11 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         GROUP = max(1, group_depth)
         dom, dom_ms = MERGED_KERNEL[launch_mode], gl_ms
         # (foam is read before the first and written after the last of a group's ticks only: 4 B/texel less for each tick in between)
-        dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C
-        per_launch = C
         T = probe - 1
         groups = -(-T // GROUP)
+        batches = max(1, round((gl_n - 1) / groups))   # tick pairs: a tick of more than 4 Mi texels is two batches, one launch each
+        per_launch = C // batches if C % batches == 0 else round(C / batches, 3)
+        dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C / batches
         total_bytes = ((k1 + k2) * T - 4 * (T - groups)) * n * n * C
         achieved = gbps(total_bytes, gl_ms * gl_n)
         contract = gbps(sum(CONTRACT_BYTES) * T * n * n * C, gl_ms * gl_n)
@@ -290,7 +291,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
                    "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
                    "launches": (f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp)"
                                 if launch_mode == "tick_groups_compact" else
-                                "tick pairs: pass 2 of tick t and pass 1 of tick t + 1 in one launch (k_tick_pair_c)") +
+                                "tick pairs: pass 2 of one batch and pass 1 of the next (the same cascades one tick later, or the tick's other cascades) in one launch (k_tick_pair_c)") +
                                "; pass1_ms / pass2_ms below are those of the same ticks launched one pass at a time" if grouped
                                else "one pair of launches per batch and tick",
                    "gather": (f"{args.gather}, every {args.gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))

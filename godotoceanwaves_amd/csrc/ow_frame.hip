@@ -105,10 +105,11 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
 template <int N, bool F32>
 static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     using TP = TickPlan<N>;
-    if (g.pair_compact) {  // tick pairs on the compact family: k_pass2c's blocks of one tick, k_pass1c's of the next
-        if (g.d2 > 1 || g.d1 > 1) return hipErrorInvalidValue;
-        g.n2 = g.d2 * g.slots * (N / kWgRows);
-        g.n1 = g.d1 * g.slots * (N / kWgRows);
+    if (g.pair_compact) {  // tick pairs on the compact family: k_pass2c's blocks of one batch, k_pass1c's of the next
+        if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
+            return hipErrorInvalidValue;
+        g.n2 = g.slots2 * (N / kWgRows);
+        g.n1 = g.slots1 * (N / kWgRows);
         if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
         launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
         return hipGetLastError();

@@ -1304,13 +1304,14 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
     }
 }
 
-// TICK PAIRS on the compact family (ow_run on the batches that family serves, up to 4 Mi texels per tick): ONE launch per tick does
-// pass 2 of tick t (k_pass2c's blocks: 8 columns) and pass 1 of tick t + 1 (k_pass1c's blocks: 8 rows) -- independent work; the
-// scratch intermediate is two ticks deep (g.tbase2[0] / g.tbase1[0]).  Chunks of 8 blocks (one block per XCD, so both block -> rows
-// maps keep their XCD placement) alternate between the two passes: a CU holds blocks of both, pass 1's exposed transform time
-// overlaps pass 2's memory time, and the launch gap and the tail of one kernel per tick are gone.  Same item bodies as k_pass1c /
-// k_pass2c: results are bit-identical to one launch pair per tick.  g.d2 / g.d1 in {0, 1}: the two ends of a run have one pass only.
-// (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 29.0 / 38.6, x 3 42.5 / 50.7, x 4 54.6 / 57.0, 512^2 x 8 28.8 / 34.8.
+// TICK PAIRS on the compact family (ow_run on the batches that family serves): the ticks of a run are a stream of batches of at
+// most 4 Mi texels (a tick of more is two batches), and ONE launch does pass 2 of one batch (k_pass2c's blocks: 8 columns) and pass 1 of
+// the NEXT batch of the stream (k_pass1c's blocks: 8 rows; the same cascades one tick later, or the tick's other cascades) --
+// independent work; the scratch intermediate is two batches deep (g.tbase2[0] / g.tbase1[0]).  Chunks of 8 blocks (one block per XCD,
+// so both block -> rows maps keep their XCD placement) alternate between the two passes: a CU holds blocks of both, pass 1's exposed
+// transform time overlaps pass 2's memory time, and the launch gap and the tail of one kernel per batch are gone.  Same item bodies
+// as k_pass1c / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the two ends of a run.
+// (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 27.6 / 38.5, x 3 42.4 / 50.6, x 4 53.4 / 57.1, 512^2 x 8 27.1 / 34.8.
 //  Deeper groups -- a block walking through 2 or 4 ticks of its columns as in k_tick_group_c_lp -- gain nothing more here and lose
 //  once the deeper scratch leaves the Infinity Cache; profiles/r02_tick_pairs_compact.txt.)
 template <int N, bool F32>
@@ -1343,13 +1344,14 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     } else {
         p1_index_to_rows<N>(index, slot, row0);
     }
-    const CascadeFrame cf = args.c[slot];
+    const int launch_slot = (first ? g.first1 : g.first2) + slot;  // slot: index inside the batch = scratch slot of its intermediate
+    const CascadeFrame cf = args.c[launch_slot];
     fetch_arguments(buf, cf);
     if (!first) {
         uint32_t foam_pk[kP / 2];
         pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
     } else {
-        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][slot], g.tbase1[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
                                                  [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
     }
 }

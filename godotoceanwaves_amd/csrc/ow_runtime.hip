@@ -69,8 +69,8 @@ struct ow_context {
     // into one group; the scratch buffers hold 2 * depth * count cascades then
     int group_p1_form = -1;
     int group_max_count = 0, group_depth = 0;
-    // ow_run's tick pairs on the compact family (k_tick_pair_c): the largest cascade count they serve; scratch two ticks deep
-    int pair_max_count = 0;
+    // ow_run's tick pairs on the compact family (k_tick_pair_c): the largest batch they launch (0 = never); scratch two batches deep
+    int pair_slots = 0;
     int last_group_depth = 0;  // ticks per launch of the most recent ow_run that went out in groups / pairs
     // timing: a pool of events so that timed ticks stay enqueued back to back
     int timing = 0;  // 0 off, 1 per pass (ow_run stays on one launch per pass), 2 as launched (tick groups / pairs stay on, timed per launch)
@@ -121,15 +121,30 @@ int batch_size(const ow_context *c, int count) {
 // (with 1 GiB instead -- depth 4 up to 1024^2 x 2 -- nothing changes where it matters: 1024^2 x 2 39.4 vs 39.4 us on k_pass1c + k_pass2c,
 // x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
 constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
-// Ticks of the compact family up to kPairTexels go out as tick pairs (k_tick_pair_c: pass 2 of tick t and pass 1 of tick t + 1 in one
-// launch), scratch two ticks deep: at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds
-// next to the spectra; beyond (1024^2 x 5, x 6) the pairs lose to one launch per pass (measured: profiles/r02_tick_pairs_compact.txt).
+// Ticks of the compact family go out as tick pairs (k_tick_pair_c: pass 2 of one batch and pass 1 of the next in one launch), in
+// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 8 is two batches (3 + 2 .. 4 + 4).  The scratch is two batches deep:
+// at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra; with 5 or 6 Mi
+// texels per batch the pairs lose to one launch per pass (measured: profiles/r02_tick_pairs_compact.txt).
 constexpr size_t kPairTexels = (size_t)4 << 20;
+// the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
+int pair_batches(const ow_context *c, int count, int *sizes) {
+    const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));
+    if (cap < 1 || count < 1 || !ow::tick_groups_supported(c->n)) return 0;
+    const int B = (count + cap - 1) / cap;
+    for (int b = 0, left = count; b < B; ++b) {
+        sizes[b] = (left + (B - b) - 1) / (B - b);
+        left -= sizes[b];
+        if (ow::kernel_family(c->n, sizes[b], c->kernel_mode) != 3) return 0;
+    }
+    return B;
+}
 void plan_tick_groups(ow_context *c, uint32_t flags) {
-    c->group_max_count = c->group_depth = c->pair_max_count = 0;
+    c->group_max_count = c->group_depth = c->pair_slots = 0;
     if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
-    for (int count = 1; count <= c->cascades; ++count)
-        if (ow::kernel_family(c->n, count, c->kernel_mode) == 3 && (size_t)count * c->n * c->n <= kPairTexels) c->pair_max_count = count;
+    for (int count = 1; count <= c->cascades; ++count) {
+        int sizes[OW_MAX_CASCADES];
+        if (pair_batches(c, count, sizes) > 0) c->pair_slots = std::max(c->pair_slots, sizes[0]);
+    }
     int best = 0;
     for (int count = 1; count <= c->cascades; ++count)
         if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;
@@ -144,7 +159,7 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
 }
 int scratch_slots(const ow_context *c) {
-    return std::max({std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count, 2 * c->pair_max_count});
+    return std::max({std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count, 2 * c->pair_slots});
 }
 
 constexpr size_t kMaxTimedBatches = 4096;
@@ -529,16 +544,17 @@ namespace {
 // Can the remaining ticks of ow_run go out as tick groups / tick pairs?  Only a batch of the layer-parallel compact family (groups)
 // or a batch of the compact family of at most kPairTexels (pairs), with nothing left
 // armed, no spectrum to regenerate, no fault to inject, no per-launch timing requested, and records that pass enqueue()'s checks.
-// returns the ticks per launch: 0 = not usable, group_depth for the tick groups, 1 for the compact family's tick pairs
+// returns 0 = not usable, the ticks per launch (group_depth) for the tick groups, -1 for the compact family's tick pairs
 int tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
     if (c->timing == 1 || c->inject_fault || c->pass_num_cascades_remaining != 0) return 0;
-    const int fam = ow::kernel_family(c->n, count, c->kernel_mode);
-    const bool groups = fam == 4 && count <= c->group_max_count, pairs = fam == 3 && count <= c->pair_max_count;
+    int sizes[OW_MAX_CASCADES];
+    const bool groups = ow::kernel_family(c->n, count, c->kernel_mode) == 4 && count <= c->group_max_count;
+    const bool pairs = !groups && c->pair_slots > 0 && pair_batches(c, count, sizes) > 0;
     if (!groups && !pairs) return 0;
     for (int i = 0; i < count; ++i)
         if (params[i].should_generate_spectrum || !finite_record(params[i]) || !(params[i].tile_length[0] > 0.0f) || !(params[i].tile_length[1] > 0.0f))
             return 0;  // (the ordinary path regenerates / reports)
-    return groups ? c->group_depth : 1;
+    return groups ? c->group_depth : -1;
 }
 
 // one more ow_update_all() worth of arithmetic on the records (wave_generator.gd:101-106); time_out[i] = FP32 time of launch
@@ -554,29 +570,8 @@ void advance_tick(double delta, ow_cascade_params *params, int count, float *tim
     }
 }
 
-// `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
-//   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
-ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D) {
-    const int groups = (ticks + D - 1) / D;
-    auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
-    auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
-    ow::TickGroupArgs ga;
-    std::memset(&ga, 0, sizeof(ga));
-    ga.slots = count;
-    ga.pair_compact = ow::kernel_family(c->n, count, c->kernel_mode) == 3;  // (then D = 1)
-    // pass-1 items: k_pass1c's form (8 rows, all layers from one load + modulation) for maps of 512^2 up and from 384 Ki texels per
-    // tick on, the layer-parallel form (more, smaller items; the spectrum is modulated once per layer) below -- measured, MI355X, us
-    // per tick lp / compact: 256^2 x 1 4.40 / 4.50, x 4 5.02 / 5.05, x 5 6.01 / 6.28, x 6 7.06 / 6.70, x 8 9.55 / 7.77;
-    // 512^2 x 1 7.25 / 7.04, x 2 10.1 / 8.5, x 4 19.4 / 15.2, x 6 31.4 / 28.1; 1024^2 x 1 19.0 / 15.8   (scripts/group_p1_body.py)
-    ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
-    // pass 1 of group 0
-    ga.d2 = 0;
-    ga.d1 = group_size(0);
-    for (int j = 0; j < ga.d1; ++j) {
-        advance_tick(delta, params, count, ga.time1[j]);
-        ga.tbase1[j] = slot_of_tick(j);
-    }
-    // the launch constants that do not change from tick to tick (same delta: same foam rates), launch slot i = cascade count-1-i
+// the launch constants that do not change from tick to tick of a run (same delta: same foam rates), launch slot i = cascade count-1-i
+ow::FrameArgs run_frame_args(const ow_cascade_params *params, int count) {
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     for (int i = 0; i < count; ++i) {
@@ -589,16 +584,54 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
         cf.foam_decay = expf(-(float)p.foam_decay_rate);
         cf.cascade = count - 1 - i;
     }
-    auto launch = [&]() -> ow_status {
-        hipEvent_t *ev = nullptr;
-        if (c->timing == 2) {
-            ow_status st = next_events(c, &ev, true);
-            if (st != OW_OK) return st;
-        }
-        OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, ow::LaunchTiming{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}));
-        return OW_OK;
-    };
-    if (ow_status st = launch(); st != OW_OK) return st;
+    return args;
+}
+ow_status launch_merged(ow_context *c, const ow::FrameArgs &args, const ow::TickGroupArgs &ga) {
+    hipEvent_t *ev = nullptr;
+    if (c->timing == 2) {  // as-launched timing: this launch's own begin -> end
+        ow_status st = next_events(c, &ev, true);
+        if (st != OW_OK) return st;
+    }
+    OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, ow::LaunchTiming{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}));
+    return OW_OK;
+}
+void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_params *params, int count, int last_batch, int family, int depth) {
+    for (int i = 0; i < count; ++i) {
+        c->pass_parameters[i] = params[i];
+        args.c[i].time = (float)params[count - 1 - i].time;
+    }
+    c->pass_count = count;
+    c->pass_num_cascades_remaining = 0;
+    c->last_args = args;
+    c->last_count = last_batch;
+    c->last_family = family;
+    c->last_group_depth = depth;
+    for (int &sl : c->slot_of) sl = -1;  // (no reference-layout intermediate to inspect after such a run)
+}
+
+// `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
+//   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
+ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D) {
+    const int groups = (ticks + D - 1) / D;
+    auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
+    auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
+    ow::TickGroupArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.slots = count;
+    // pass-1 items: k_pass1c's form (8 rows, all layers from one load + modulation) for maps of 512^2 up and from 384 Ki texels per
+    // tick on, the layer-parallel form (more, smaller items; the spectrum is modulated once per layer) below -- measured, MI355X, us
+    // per tick lp / compact: 256^2 x 1 4.40 / 4.50, x 4 5.02 / 5.05, x 5 6.01 / 6.28, x 6 7.06 / 6.70, x 8 9.55 / 7.77;
+    // 512^2 x 1 7.25 / 7.04, x 2 10.1 / 8.5, x 4 19.4 / 15.2, x 6 31.4 / 28.1; 1024^2 x 1 19.0 / 15.8   (scripts/group_p1_body.py)
+    ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
+    // pass 1 of group 0
+    ga.d2 = 0;
+    ga.d1 = group_size(0);
+    for (int j = 0; j < ga.d1; ++j) {
+        advance_tick(delta, params, count, ga.time1[j]);
+        ga.tbase1[j] = slot_of_tick(j);
+    }
+    ow::FrameArgs args = run_frame_args(params, count);
+    if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
     for (int g = 0; g < groups; ++g) {
         ga.d2 = group_size(g);
         for (int j = 0; j < ga.d2; ++j) ga.tbase2[j] = slot_of_tick(g * D + j);
@@ -607,19 +640,48 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
             advance_tick(delta, params, count, ga.time1[j]);
             ga.tbase1[j] = slot_of_tick((g + 1) * D + j);
         }
-        if (ow_status st = launch(); st != OW_OK) return st;
+        if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
     }
-    for (int i = 0; i < count; ++i) {
-        c->pass_parameters[i] = params[i];
-        args.c[i].time = (float)params[count - 1 - i].time;
+    finish_merged_run(c, args, params, count, count, 5, D);
+    return OW_OK;
+}
+
+// `ticks` >= 2 consecutive ow_update_all() ticks of the compact family as tick pairs: the run is a stream of batches (B per tick, launch
+// slots in the order ow_update_all takes them), launch i = [pass 2 of batch i - 1 + pass 1 of batch i]; batch i's intermediate lives in
+// scratch slots (i mod 2) * pair_slots ...
+ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
+    int sizes[OW_MAX_CASCADES], first[OW_MAX_CASCADES];
+    const int B = pair_batches(c, count, sizes);
+    for (int b = 0, at = 0; b < B; ++b) {
+        first[b] = at;
+        at += sizes[b];
     }
-    c->pass_count = count;
-    c->pass_num_cascades_remaining = 0;
-    c->last_args = args;
-    c->last_count = count;
-    c->last_family = ga.pair_compact ? 6 : 5;
-    c->last_group_depth = D;
-    for (int &sl : c->slot_of) sl = -1;  // (no reference-layout intermediate to inspect after such a run)
+    ow::TickGroupArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.pair_compact = 1;
+    ow::FrameArgs args;
+    const int total = ticks * B;
+    for (int i = 0; i <= total; ++i) {
+        ga.slots2 = ga.slots1 = 0;
+        if (i >= 1) {
+            const int b = (i - 1) % B;
+            ga.first2 = first[b];
+            ga.slots2 = sizes[b];
+            ga.tbase2[0] = ((i - 1) & 1) * c->pair_slots;
+        }
+        if (i < total) {
+            const int b = i % B;
+            if (b == 0) advance_tick(delta, params, count, ga.time1[0]);  // a new tick begins: every launch slot's time
+            if (i == 0) args = run_frame_args(params, count);             // (after the first advance: the foam rates of this delta)
+            ga.first1 = first[b];
+            ga.slots1 = sizes[b];
+            ga.tbase1[0] = (i & 1) * c->pair_slots;
+        }
+        ga.d2 = ga.slots2 > 0;
+        ga.d1 = ga.slots1 > 0;
+        if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
+    }
+    finish_merged_run(c, args, params, count, sizes[B - 1], 6, 1);
     return OW_OK;
 }
 
@@ -637,9 +699,9 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     }
     // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
     const int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
-    if (depth > 0) {
+    if (depth != 0) {
         OW_HIP(hipSetDevice(c->device));
-        ow_status st = run_tick_groups(c, delta, params, count, frames - f, depth);
+        ow_status st = depth > 0 ? run_tick_groups(c, delta, params, count, frames - f, depth) : run_tick_pairs(c, delta, params, count, frames - f);
         if (st != OW_OK) return st;
         f = frames;
     }

@@ -1,5 +1,5 @@
-"""ow_run on a batch of the compact family of at most 4 Mi texels per tick goes out in TICK PAIRS (k_tick_pair_c: pass 2 of tick t and pass 1
-of tick t + 1 in one launch, the compact family's own item bodies) -- held to one launch per pass BITWISE below, too.
+"""ow_run on the compact family (map sizes up to 1024^2) goes out in TICK PAIRS (k_tick_pair_c: pass 2 of one batch of at most 4 Mi texels and
+pass 1 of the next batch of the run in one launch, the compact family's own item bodies) -- held to one launch per pass BITWISE below, too.
 ow_run on a small batch: from the second tick on, pass 2 of tick k and pass 1 of tick k + 1 go out in ONE launch (k_tick_group_c_lp;
 the two are independent, the scratch intermediate is double-buffered by tick parity) -- against the same ticks as one pair of
 launches each.  Same lane code in the same order per texel, so the comparison is BITWISE; the golden 1000-frame loop
@@ -59,7 +59,8 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, mon
     same_maps(a, b, len(ids))
 
 
-@pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7])])
+@pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7]),
+                                   (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]), (1024, [0, 1, 2, 3, 4, 5, 6, 7])])  # two batches per tick: 3 + 2, 4 + 3, 4 + 4
 @pytest.mark.parametrize("frames", [2, 3, 4, 9])
 def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
     a, pa = make(n, ids, True)
@@ -158,10 +159,10 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
     a.sync(); b.sync()
     assert a.last_kernel_family() == "tick_groups_compact"
     same_maps(a, b, len(ids))
-    big, pbig = make(1024, [0, 1, 2, 3, 4], True)   # 5 Mi texels per tick: beyond the tick pairs as well
+    big, pbig = make(2048, [0, 1], True)   # rows that span two waves: no merged launches
     big.run(UPDATE_DELTA, pbig, 4)
     big.sync()
-    assert big.last_kernel_family() == "compact"
+    assert big.last_kernel_family() == "compact" and big.tick_group_depth() == 0
 
 
 def test_tick_groups_interleaved_with_the_reference_schedule_and_changing_counts():
