@@ -267,7 +267,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     tick_bpt = (dom_bpt / max(1, group_depth)) if grouped else (k1 + k2)
     tick_moved = tick_bpt * n * n * C / tick_s / 1e9          # per GPU
     tick_contract = sum(CONTRACT_BYTES) * n * n * C / tick_s / 1e9
-    traffic = None if grouped else pmc_traffic(dom, n, per_launch)
+    traffic = pmc_traffic(dom, n, per_launch)  # (per FULL launch of the merged kernels)
     headline = (n, C) == (1024, 4)
     out = {
         "metric": "displacement+normal maps/sec, 1024^2 x 4 cascades; achieved HBM GB/s vs peak" if headline else

@@ -122,10 +122,13 @@ int batch_size(const ow_context *c, int count) {
 // x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
 constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 // Ticks of the compact family go out as tick pairs (k_tick_pair_c: pass 2 of one batch and pass 1 of the next in one launch), in
-// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 8 is two batches (3 + 2 .. 4 + 4).  The scratch is two batches deep:
-// at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra; with 5 or 6 Mi
-// texels per batch the pairs lose to one launch per pass (measured: profiles/r02_tick_pairs_compact.txt).
-constexpr size_t kPairTexels = (size_t)4 << 20;
+// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 or x 6 is two batches (3 + 2, 3 + 3).  The scratch is two batches deep:
+// at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra (12 B/texel of
+// every cascade of the tick, read once per tick).  Where the two together exceed kPairResidentBytes the pairs are off: measured,
+// 1024^2 x 8 (96 MiB of spectra + 160 MiB) 115.5 - 125.0 us per tick in pairs, varying from context to context, against a steady
+// 114.0 - 114.8 with one launch per pass, which keeps one batch of intermediate in flight; a single batch of 5 or 6 Mi texels
+// loses as well (profiles/r02_tick_pairs_compact.txt).
+constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)224 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));
@@ -136,6 +139,8 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
         left -= sizes[b];
         if (ow::kernel_family(c->n, sizes[b], c->kernel_mode) != 3) return 0;
     }
+    const size_t pl = (size_t)c->n * c->n;  // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
+    if (B > 1 && 12 * pl * count + 2 * 20 * pl * sizes[0] > kPairResidentBytes) return 0;
     return B;
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
