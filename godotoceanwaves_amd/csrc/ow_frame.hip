@@ -101,19 +101,22 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
     return hipGetLastError();
 }
 
+// ---- tick pairs on the compact family (k_tick_pair_c): k_pass2c's blocks of one batch, k_pass1c's of the next, in one launch ----
+template <int N, bool F32>
+static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
+    if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
+        return hipErrorInvalidValue;
+    g.n2 = g.slots2 * (N / kWgRows);
+    g.n1 = g.slots1 * (N / kWgRows);
+    if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
+    launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+    return hipGetLastError();
+}
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----
 template <int N, bool F32>
 static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     using TP = TickPlan<N>;
-    if (g.pair_compact) {  // tick pairs on the compact family: k_pass2c's blocks of one batch, k_pass1c's of the next
-        if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
-            return hipErrorInvalidValue;
-        g.n2 = g.slots2 * (N / kWgRows);
-        g.n1 = g.slots1 * (N / kWgRows);
-        if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-        launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
-        return hipGetLastError();
-    }
+    if (g.pair_compact) return launch_pair_n<N, F32>(args, g, buf, s, lt);
     g.n2 = g.d2 > 0 ? TP::items_2(g.slots) : 0;
     g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;
@@ -122,6 +125,7 @@ static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const D
     return hipGetLastError();
 }
 bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+bool tick_pairs_supported(int n) { return tick_groups_supported(n) || n == 2048; }
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
 #define OW_GROUP(NN) \
@@ -130,6 +134,9 @@ hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &
         OW_GROUP(256)
         OW_GROUP(512)
         OW_GROUP(1024)
+        case 2048:
+            if (!g.pair_compact) break;
+            return buf.f32 ? launch_pair_n<2048, true>(args, g, buf, s, lt) : launch_pair_n<2048, false>(args, g, buf, s, lt);
     }
 #undef OW_GROUP
     return hipErrorInvalidValue;

@@ -748,11 +748,12 @@ __device__ __forceinline__ void split_tw_commit(const SplitTw<SG> &p, cplx *tw_l
     lds_barrier();
 }
 
-template <int N, int ROWS = OW_SPLIT_P1_ROWS, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
-__global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_split(DeviceBuffers buf, FrameArgs args) {
+// one block of the split-plan pass 1 = rows row0 .. row0 + ROWS - 1 of launch slot `tslot` (scratch) / cascade cf.cascade at time `time`;
+// lds: SplitGeo::kLdsCplx + plan_sync_flag_cplx(N, ROWS) complex values.  Shared by k_pass1c_split and the 2048^2 form of k_tick_pair_c.
+template <int N, int ROWS, int AUX_T, int AUX_H>
+__device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int fault, cplx *lds) {
     using SG = SplitGeo<N, ROWS>;
     constexpr int H = SG::H, TH = SG::TH, P = kP, LC = Pass1<N>::kCompactLayers, T = plan_T(N);
-    __shared__ __attribute__((aligned(16))) cplx lds[SG::kLdsCplx + plan_sync_flag_cplx(N, ROWS)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + SG::TW;
     const int tau = threadIdx.x;
@@ -764,19 +765,15 @@ __global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_spl
     RowSync<N> pair;  // the two waves of a row (used by the pair that owns texel row 0 only)
     int *sync_flags = reinterpret_cast<int *>(lds + SG::kLdsCplx);
     pair.attach(sync_flags, rw, w);
-    pair.watch(buf.status, args.c[0].fault);
+    pair.watch(buf.status, fault);
     if ((int)threadIdx.x < 2 * ROWS) sync_flags[threadIdx.x] = 0;  // made visible by the block barrier of the twiddle commit
 
-    int slot, row0;
-    p1_block_to_rows<N, kWgRows / ROWS>(slot, row0);
-    const CascadeFrame cf = args.c[slot];
-    fetch_arguments(buf, cf);
     const int y = row0 + rw;
     const GBuf h0_c = make_gbuf(buf.h0 + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf om_c = make_gbuf(buf.omega + (size_t)cf.cascade * plane, plane * 4u);
-    const GBuf T_c = make_gbuf(buf.T + (size_t)slot * plane * kLayers, t_cascade_bytes(N));
-    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)slot * N, (uint32_t)N * 8u);
-    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)slot * N * 4, (uint32_t)N * 32u);
+    const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
+    const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
+    const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
 
     // storing thread: row q of the block, x' = xi + T m (and + N/2): W_N^xi from the table, the ordinal part is compile time
     const int q = tau % ROWS, xi = tau / ROWS;  // xi in [0, T)
@@ -790,7 +787,7 @@ __global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_spl
         float om[P];
         Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
         split_tw_commit<SG>(twv, tw_lds);
-        Pass1<N>::modulate(h, a, b, om, cf.time);
+        Pass1<N>::modulate(h, a, b, om, time);
     }
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
@@ -905,6 +902,17 @@ __global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_spl
             for (int g = 0; g < 4; ++g) store_chunk(L, g);
         }
     }
+}
+
+template <int N, int ROWS = OW_SPLIT_P1_ROWS, int AUX_T = kAuxDefault, int AUX_H = kAuxDefault>
+__global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_split(DeviceBuffers buf, FrameArgs args) {
+    using SG = SplitGeo<N, ROWS>;
+    __shared__ __attribute__((aligned(16))) cplx lds[SG::kLdsCplx + plan_sync_flag_cplx(N, ROWS)];
+    int slot, row0;
+    p1_block_to_rows<N, kWgRows / ROWS>(slot, row0);
+    const CascadeFrame cf = args.c[slot];
+    fetch_arguments(buf, cf);
+    pass1c_split_item<N, ROWS, AUX_T, AUX_H>(buf, cf, cf.time, slot, row0, args.c[0].fault, lds);
 }
 
 // ===================================================================================================
@@ -1310,19 +1318,18 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
 // independent work; the scratch intermediate is two batches deep (g.tbase2[0] / g.tbase1[0]).  Chunks of 8 blocks (one block per XCD,
 // so both block -> rows maps keep their XCD placement) alternate between the two passes: a CU holds blocks of both, pass 1's exposed
 // transform time overlaps pass 2's memory time, and the launch gap and the tail of one kernel per batch are gone.  Same item bodies
-// as k_pass1c / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the two ends of a run.
+// as k_pass1c (k_pass1c_split at 2048^2) / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the
+// two ends of a run.
 // (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 27.6 / 38.5, x 3 42.4 / 50.6, x 4 53.4 / 57.1, 512^2 x 8 27.1 / 34.8.
 //  Deeper groups -- a block walking through 2 or 4 ticks of its columns as in k_tick_group_c_lp -- gain nothing more here and lose
 //  once the deeper scratch leaves the Infinity Cache; profiles/r02_tick_pairs_compact.txt.)
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
-    static_assert(!plan_row_spans_waves(N), "N <= 1024");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
-    RowSync<N> rs;
-    TwPrefetch<N> twp;
-    tw_fetch<N>(twp, buf.tw);
+    constexpr bool kSplit = plan_split(N);  // N = 2048: pass 1 is the split plan's block (k_pass1c_split), rows of pass 2 span two waves
+    using SG = SplitGeo<N, kWgRows>;
+    static_assert(!kSplit || SG::kThreads == plan_wg_threads(N), "both passes' blocks have the same number of threads");
+    constexpr int kLds2 = plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows), kLds1 = kSplit ? SG::kLdsCplx + plan_sync_flag_cplx(N, kWgRows) : kLds2;
+    __shared__ __attribute__((aligned(16))) cplx lds[kLds1 > kLds2 ? kLds1 : kLds2];
     // g.n2 pass-2 blocks and g.n1 pass-1 blocks (multiples of 8, either may be 0): alternate in chunks of 8 while both last
     int index = blockIdx.x;
     bool first;  // is this a pass-1 block?
@@ -1346,12 +1353,29 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     }
     const int launch_slot = (first ? g.first1 : g.first2) + slot;  // slot: index inside the batch = scratch slot of its intermediate
     const CascadeFrame cf = args.c[launch_slot];
+    if constexpr (kSplit) {
+        if (first) {
+            fetch_arguments(buf, cf);
+            pass1c_split_item<N, kWgRows, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, 0, lds);
+            return;
+        }
+    }
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    const int tau = threadIdx.x;
+    RowSync<N> rs;
+    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
+    rs.watch(buf.status, 0);
+    init_row_sync<N>(sync_flags, kWgRows);
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
     fetch_arguments(buf, cf);
     if (!first) {
         uint32_t foam_pk[kP / 2];
-        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
-    } else {
-        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
+    } else if constexpr (!kSplit) {
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, tau, tw_lds, rows_lds, rs,
                                                  [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
     }
 }

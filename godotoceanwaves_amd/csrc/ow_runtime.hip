@@ -132,7 +132,7 @@ constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)224
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));
-    if (cap < 1 || count < 1 || !ow::tick_groups_supported(c->n)) return 0;
+    if (cap < 1 || count < 1 || !ow::tick_pairs_supported(c->n)) return 0;
     const int B = (count + cap - 1) / cap;
     for (int b = 0, left = count; b < B; ++b) {
         sizes[b] = (left + (B - b) - 1) / (B - b);
@@ -140,16 +140,18 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
         if (ow::kernel_family(c->n, sizes[b], c->kernel_mode) != 3) return 0;
     }
     const size_t pl = (size_t)c->n * c->n;  // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
-    if (B > 1 && 12 * pl * count + 2 * 20 * pl * sizes[0] > kPairResidentBytes) return 0;
+    const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
+    if (B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) return 0;
     return B;
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
-    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
+    if (flags & OW_FLAG_NO_TICK_GROUPS) return;
     for (int count = 1; count <= c->cascades; ++count) {
         int sizes[OW_MAX_CASCADES];
         if (pair_batches(c, count, sizes) > 0) c->pair_slots = std::max(c->pair_slots, sizes[0]);
     }
+    if (!ow::tick_groups_supported(c->n)) return;
     int best = 0;
     for (int count = 1; count <= c->cascades; ++count)
         if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;

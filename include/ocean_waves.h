@@ -94,8 +94,9 @@ typedef struct ow_config {
  *    consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
  *    (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled
  *    by several (k_tick_group_c_lp);
- *  - TICK PAIRS, batches of the compact family of at most 4 Mi texels per tick (1024^2 x 2 .. 4, 512^2 x 7 ..): one launch per tick
- *    does pass 2 of tick t and pass 1 of tick t + 1 (k_tick_pair_c).
+ *  - TICK PAIRS, the compact family (1024^2 x 2 .. 6, 512^2 x 7 .., 2048^2 x 1 and x 4): the run is a stream of batches of at most 4 Mi
+ *    texels and one launch does pass 2 of one batch and pass 1 of the next -- the same cascades one tick later, or the tick's other
+ *    cascades (k_tick_pair_c).
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
  * (Measurement knob, read by ow_create: the environment variable OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" forces one of the two forms of
  * the groups' pass-1 work items; unset, the runtime picks by batch size.  Results do not depend on it.) */

@@ -60,7 +60,8 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, mon
 
 
 @pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7]),
-                                   (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5])])  # two batches per tick: 3 + 2, 3 + 3
+                                   (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5]),  # two batches per tick: 3 + 2, 3 + 3
+                                   (2048, [2]), (2048, [0, 1, 2, 3])])                   # split-plan pass 1, rows of pass 2 span two waves; one cascade per batch
 @pytest.mark.parametrize("frames", [2, 3, 4, 9])
 def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
     a, pa = make(n, ids, True)
@@ -159,7 +160,7 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
     a.sync(); b.sync()
     assert a.last_kernel_family() == "tick_groups_compact"
     same_maps(a, b, len(ids))
-    for n_big, ids_big in ((2048, [0, 1]), (1024, list(range(8)))):  # rows that span two waves; spectra + two batches beyond the cache budget
+    for n_big, ids_big in ((2048, [0, 1]), (1024, list(range(8)))):  # one batch at a time fits the cache budget next to the spectra, two do not
         big, pbig = make(n_big, ids_big, True)
         big.run(UPDATE_DELTA, pbig, 4)
         big.sync()
