@@ -124,10 +124,11 @@ constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 // Ticks of the compact family go out as tick pairs (k_tick_pair_c: pass 2 of one batch and pass 1 of the next in one launch), in
 // equal batches of at most kPairTexels -- a tick of 1024^2 x 5 or x 6 is two batches (3 + 2, 3 + 3).  The scratch is two batches deep:
 // at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra (12 B/texel of
-// every cascade of the tick, read once per tick).  Where the two together exceed kPairResidentBytes the pairs are off: measured,
-// 1024^2 x 8 (96 MiB of spectra + 160 MiB) 115.5 - 125.0 us per tick in pairs, varying from context to context, against a steady
-// 114.0 - 114.8 with one launch per pass, which keeps one batch of intermediate in flight; a single batch of 5 or 6 Mi texels
-// loses as well (profiles/r02_tick_pairs_compact.txt).
+// every cascade of the tick, read once per tick).  Two-batch ticks are off where ONE batch of intermediate next to the spectra fits
+// kPairResidentBytes and two do not: measured, 1024^2 x 8 (96 MiB of spectra + 160 MiB) 115.5 - 125.0 us per tick in pairs, varying
+// from context to context, against a steady 114.0 - 114.8 with one launch per pass.  Where not even one batch fits (2048^2 x 4: 192 MiB
+// of spectra) there is nothing to lose: 277 -> 268.5 us in pairs.  A single batch of 5 or 6 Mi texels loses as well
+// (profiles/r02_tick_pairs_compact.txt).
 constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)224 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
