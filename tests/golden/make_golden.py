@@ -24,6 +24,9 @@ CASES = [  # (map_size, cascade preset id, frames, row stride of the stored maps
     (512, 3, 2, 16),
     (1024, 2, 2, 64),
     (1024, 0, 1, 64),
+    # three frames: what ow_run(3) leaves behind after one ordinary tick and two merged launches (tick groups / tick pairs)
+    (512, 3, 3, 16),
+    (1024, 2, 3, 64),
 ]
 
 

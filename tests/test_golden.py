@@ -73,6 +73,38 @@ def test_large_batch_compact_kernels_match_reference_shader_outputs(path):
     assert np.abs(foam - foam_ref).max() <= H.TOL_FOAM_ABS
 
 
+def _check_maps(gen, layer, z):
+    stride = int(z["row_stride"])
+    disp, norm = gen.get_maps(layer)
+    assert H.fp16_close(disp[::stride], z["displacement"]) <= 1.0
+    assert H.fp16_close(norm[::stride][..., :3], z["normal"][..., :3]) <= 1.0
+    foam, foam_ref = norm[::stride][..., 3].view(np.float16).astype(np.float64), z["normal"][..., 3].view(np.float16).astype(np.float64)
+    assert np.abs(foam - foam_ref).max() <= H.TOL_FOAM_ABS
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if p.endswith("_f3.npz") and ("n1024" in p or "n512" in p)], ids=lambda p: os.path.basename(p))
+@pytest.mark.parametrize("batch", ["alone", "full"])
+def test_merged_launches_of_ow_run_match_reference_shader_outputs(path, batch):
+    """ow_run(3) = one ordinary tick + two ticks that go out merged across ticks; what it leaves behind is held against the bytes the
+    reference's own shaders produced after three updates.  "alone": the fixture's cascade on its own -- the tick groups
+    (k_tick_group_c_lp); "full": as one of a batch of the compact family (1024^2 x 4, 512^2 x 8) -- the tick pairs (k_tick_pair_c),
+    the form the headline configuration is measured in."""
+    z = np.load(path)
+    n, ci, frames = int(z["map_size"]), int(z["cascade"]), int(z["frames"])
+    assert frames == 3
+    count = 1 if batch == "alone" else (4 if n == 1024 else 8)
+    others = [c for c in range(8) if c != ci]
+    ids = (others[:1] + [ci] + others[1:])[:count] if count > 1 else [ci]
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.init_gpu(max(2, count))
+    params = [WaveCascadeParameters(**cascade_preset(c)) for c in ids]
+    gen.run(float(z["delta"]), params, frames)
+    gen.sync()
+    assert gen.last_kernel_family() == ("tick_groups_compact" if batch == "alone" else "tick_pairs_compact")
+    _check_maps(gen, ids.index(ci), z)
+
+
 def test_thousand_frame_loop_matches_oracle_trajectory():
     """BASELINE config 2: 256^2 x 4 cascades, 1000-frame loop (dispersion + IFFT + foam accumulate).  The fixture
     (tests/golden/make_long_golden.py) is the CPU oracle's state after the same 1000 updates; the foam channel is
