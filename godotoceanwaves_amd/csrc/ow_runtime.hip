@@ -122,14 +122,15 @@ int batch_size(const ow_context *c, int count) {
 // x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
 constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 // Ticks of the compact family go out as tick pairs (k_tick_pair_c: pass 2 of one batch and pass 1 of the next in one launch), in
-// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 or x 6 is two batches (3 + 2, 3 + 3).  The scratch is two batches deep:
+// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 7 is two batches (3 + 2, 3 + 3, 4 + 3).  The scratch is two batches deep:
 // at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra (12 B/texel of
-// every cascade of the tick, read once per tick).  Two-batch ticks are off where ONE batch of intermediate next to the spectra fits
-// kPairResidentBytes and two do not: measured, 1024^2 x 8 (96 MiB of spectra + 160 MiB) 115.5 - 125.0 us per tick in pairs, varying
-// from context to context, against a steady 114.0 - 114.8 with one launch per pass.  Where not even one batch fits (2048^2 x 4: 192 MiB
-// of spectra) there is nothing to lose: 277 -> 268.5 us in pairs.  A single batch of 5 or 6 Mi texels loses as well
+// every cascade of the tick, read once per tick).  Multi-batch ticks are off where ONE batch of intermediate next to the spectra fits
+// kPairResidentBytes and two do not -- the line sits between what was measured on either side (us per tick, pairs | one launch per
+// pass): 1024^2 x 7 (84 MiB of spectra + 160 MiB) 103.0 | 109.2 steady; x 8 (96 + 160) 115.5 - 125.0, varying from context to context,
+// | 114.0 - 114.8; 2048^2 x 2 (96 + 160) 132.9 | 129.8; x 3 (144 + 160) 202.3 | 194 - 202.  Where not even one batch fits (2048^2 x 4:
+// 192 MiB of spectra) there is nothing to lose: 277 -> 268.5 in pairs.  A single batch of 5 or 6 Mi texels loses as well
 // (profiles/r02_tick_pairs_compact.txt).
-constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)224 << 20;
+constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));

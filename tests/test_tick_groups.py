@@ -60,7 +60,7 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, mon
 
 
 @pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7]),
-                                   (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5]),  # two batches per tick: 3 + 2, 3 + 3
+                                   (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]),  # two batches per tick: 3 + 2, 4 + 3
                                    (2048, [2]), (2048, [0, 1, 2, 3])])                   # split-plan pass 1, rows of pass 2 span two waves; one cascade per batch
 @pytest.mark.parametrize("frames", [2, 3, 4, 9])
 def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
