@@ -125,7 +125,6 @@ static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const D
     return hipGetLastError();
 }
 bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
-bool tick_pairs_supported(int n) { return tick_groups_supported(n) || n == 2048; }
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
 #define OW_GROUP(NN) \
@@ -134,9 +133,6 @@ hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &
         OW_GROUP(256)
         OW_GROUP(512)
         OW_GROUP(1024)
-        case 2048:
-            if (!g.pair_compact) break;
-            return buf.f32 ? launch_pair_n<2048, true>(args, g, buf, s, lt) : launch_pair_n<2048, false>(args, g, buf, s, lt);
     }
 #undef OW_GROUP
     return hipErrorInvalidValue;

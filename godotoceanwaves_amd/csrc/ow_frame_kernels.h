@@ -221,7 +221,9 @@ __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cp
 template <int N, int SUB = 1>
 __device__ __forceinline__ void p1_index_to_rows(int index, int &slot, int &row0) {
     constexpr int G = N / 16;  // 16-row groups per cascade; 2*G blocks per cascade
-    const int b = index / SUB, x = b & 7, i = b >> 3;
+    // (SUB > 1: the SUB blocks of one 8-row unit follow each other on the SAME XCD -- indices 8 apart --, so that their pieces of a
+    //  64-byte segment of T meet in one L2)
+    const int sub = (index >> 3) % SUB, b = ((index >> 3) / SUB) * 8 + (index & 7), x = b & 7, i = b >> 3;
     if constexpr (G >= 16) {
         constexpr int PER = G / 4;  // blocks per XCD per cascade: G/16 mirror pairs x 2 groups x 2 halves
         slot = i / PER;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void p1_index_to_rows(int index, int &slot, int &row0
         slot = grow / N;
         row0 = grow % N;
     }
-    if constexpr (SUB > 1) row0 += (index % SUB) * (kWgRows / SUB);
+    if constexpr (SUB > 1) row0 += sub * (kWgRows / SUB);
 }
 template <int N, int SUB = 1>
 __device__ __forceinline__ void p1_block_to_rows(int &slot, int &row0) {
@@ -709,13 +711,19 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
 // ===================================================================================================
 // SPLIT-PLAN compact pass 1 for N = 2048 (see "SPLIT PLAN" in ow_device.h): a row is two waves, one per parity of the element
 // index, each running the N/2 plan on its own; the radix-2 step that joins them is done by the storing threads, so the layer
-// transforms need no rendezvous between the waves of a row.  Block = 8 rows = 16 waves; wave 2r + w = parity w of row r.
+// transforms need no rendezvous between the waves of a row.  Block = ROWS rows = 2 ROWS waves; wave 2r + w = parity w of row r.
 // Twiddles: buf.tw_split = [table of the N/2 plan][W_N^k, k = 0 .. N/2 - 1].
 // (Measured on the same box: 33.5 us per 2048^2 cascade against 36.0 for k_pass1c<2048>, whose rows exchange across their two
 // waves four times per transform; x 4: 39.4 against 42.2.)
+// ROWS = 4 (OW_SPLIT_P1_ROWS): two independent 8-wave blocks per CU (74 KB of LDS each) instead of one 16-wave block whose block
+// barriers march the whole CU through load -> transform -> store in step.  A block then writes 32-byte halves of T's 64-byte
+// segments, and that only pays when the two blocks of an 8-row unit run on the SAME XCD, one after the other, so that the halves
+// meet in one L2 (p1_index_to_rows: indices 8 apart): 34.1 -> 29.3 - 30.9 us per 2048^2 cascade, 2048^2 x 4 277 -> 252 - 254 us per
+// tick.  (With the halves on neighbouring XCDs -- consecutive block indices, round 2's first attempt -- 4-row blocks lost; 2-row
+// blocks, 16-byte pieces: 39.7 us.  profiles/r02_2048_split_plan.txt)
 // ===================================================================================================
 #ifndef OW_SPLIT_P1_ROWS
-#define OW_SPLIT_P1_ROWS 8
+#define OW_SPLIT_P1_ROWS 4
 #endif
 template <int N, int ROWS = kWgRows>
 struct SplitGeo {
@@ -749,7 +757,7 @@ __device__ __forceinline__ void split_tw_commit(const SplitTw<SG> &p, cplx *tw_l
 }
 
 // one block of the split-plan pass 1 = rows row0 .. row0 + ROWS - 1 of launch slot `tslot` (scratch) / cascade cf.cascade at time `time`;
-// lds: SplitGeo::kLdsCplx + plan_sync_flag_cplx(N, ROWS) complex values.  Shared by k_pass1c_split and the 2048^2 form of k_tick_pair_c.
+// lds: SplitGeo::kLdsCplx + plan_sync_flag_cplx(N, ROWS) complex values.
 template <int N, int ROWS, int AUX_T, int AUX_H>
 __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int fault, cplx *lds) {
     using SG = SplitGeo<N, ROWS>;
@@ -1318,18 +1326,21 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
 // independent work; the scratch intermediate is two batches deep (g.tbase2[0] / g.tbase1[0]).  Chunks of 8 blocks (one block per XCD,
 // so both block -> rows maps keep their XCD placement) alternate between the two passes: a CU holds blocks of both, pass 1's exposed
 // transform time overlaps pass 2's memory time, and the launch gap and the tail of one kernel per batch are gone.  Same item bodies
-// as k_pass1c (k_pass1c_split at 2048^2) / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the
-// two ends of a run.
+// as k_pass1c / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the two ends of a run.
 // (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 27.6 / 38.5, x 3 42.4 / 50.6, x 4 53.4 / 57.1, 512^2 x 8 27.1 / 34.8.
 //  Deeper groups -- a block walking through 2 or 4 ticks of its columns as in k_tick_group_c_lp -- gain nothing more here and lose
-//  once the deeper scratch leaves the Infinity Cache; profiles/r02_tick_pairs_compact.txt.)
+//  once the deeper scratch leaves the Infinity Cache.  A 2048^2 form (k_pass2c's 16-wave blocks with k_pass1c_split's) was built and
+//  gained 3 % at x 4; the 4-row split blocks gain 8 % and need a different block size than pass 2: N <= 1024 only.
+//  profiles/r02_tick_pairs_compact.txt)
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
-    constexpr bool kSplit = plan_split(N);  // N = 2048: pass 1 is the split plan's block (k_pass1c_split), rows of pass 2 span two waves
-    using SG = SplitGeo<N, kWgRows>;
-    static_assert(!kSplit || SG::kThreads == plan_wg_threads(N), "both passes' blocks have the same number of threads");
-    constexpr int kLds2 = plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows), kLds1 = kSplit ? SG::kLdsCplx + plan_sync_flag_cplx(N, kWgRows) : kLds2;
-    __shared__ __attribute__((aligned(16))) cplx lds[kLds1 > kLds2 ? kLds1 : kLds2];
+    static_assert(!plan_row_spans_waves(N), "N <= 1024");
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
+    cplx *tw_lds = lds;
+    cplx *rows_lds = lds + plan_tw_total(N);
+    RowSync<N> rs;
+    TwPrefetch<N> twp;
+    tw_fetch<N>(twp, buf.tw);
     // g.n2 pass-2 blocks and g.n1 pass-1 blocks (multiples of 8, either may be 0): alternate in chunks of 8 while both last
     int index = blockIdx.x;
     bool first;  // is this a pass-1 block?
@@ -1353,29 +1364,12 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     }
     const int launch_slot = (first ? g.first1 : g.first2) + slot;  // slot: index inside the batch = scratch slot of its intermediate
     const CascadeFrame cf = args.c[launch_slot];
-    if constexpr (kSplit) {
-        if (first) {
-            fetch_arguments(buf, cf);
-            pass1c_split_item<N, kWgRows, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, 0, lds);
-            return;
-        }
-    }
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
-    const int tau = threadIdx.x;
-    RowSync<N> rs;
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
-    rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
-    rs.watch(buf.status, 0);
-    init_row_sync<N>(sync_flags, kWgRows);
-    TwPrefetch<N> twp;
-    tw_fetch<N>(twp, buf.tw);
     fetch_arguments(buf, cf);
     if (!first) {
         uint32_t foam_pk[kP / 2];
-        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
-    } else if constexpr (!kSplit) {
-        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, tau, tw_lds, rows_lds, rs,
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
+    } else {
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
                                                  [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
     }
 }

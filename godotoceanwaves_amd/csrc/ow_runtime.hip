@@ -127,14 +127,13 @@ constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 // every cascade of the tick, read once per tick).  Multi-batch ticks are off where ONE batch of intermediate next to the spectra fits
 // kPairResidentBytes and two do not -- the line sits between what was measured on either side (us per tick, pairs | one launch per
 // pass): 1024^2 x 7 (84 MiB of spectra + 160 MiB) 103.0 | 109.2 steady; x 8 (96 + 160) 115.5 - 125.0, varying from context to context,
-// | 114.0 - 114.8; 2048^2 x 2 (96 + 160) 132.9 | 129.8; x 3 (144 + 160) 202.3 | 194 - 202.  Where not even one batch fits (2048^2 x 4:
-// 192 MiB of spectra) there is nothing to lose: 277 -> 268.5 in pairs.  A single batch of 5 or 6 Mi texels loses as well
-// (profiles/r02_tick_pairs_compact.txt).
+// | 114.0 - 114.8.  A single batch of 5 or 6 Mi texels loses as well.  Map sizes up to 1024^2 (at 2048^2 the two passes want blocks of
+// different sizes; profiles/r02_tick_pairs_compact.txt).
 constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));
-    if (cap < 1 || count < 1 || !ow::tick_pairs_supported(c->n)) return 0;
+    if (cap < 1 || count < 1 || !ow::tick_groups_supported(c->n)) return 0;
     const int B = (count + cap - 1) / cap;
     for (int b = 0, left = count; b < B; ++b) {
         sizes[b] = (left + (B - b) - 1) / (B - b);
@@ -148,12 +147,11 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
-    if (flags & OW_FLAG_NO_TICK_GROUPS) return;
+    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
     for (int count = 1; count <= c->cascades; ++count) {
         int sizes[OW_MAX_CASCADES];
         if (pair_batches(c, count, sizes) > 0) c->pair_slots = std::max(c->pair_slots, sizes[0]);
     }
-    if (!ow::tick_groups_supported(c->n)) return;
     int best = 0;
     for (int count = 1; count <= c->cascades; ++count)
         if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;
