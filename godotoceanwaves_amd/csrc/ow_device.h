@@ -527,6 +527,7 @@ constexpr uint32_t kStatusRowSyncTimeout = 1u;  // a wave-pair rendezvous (RowSy
 constexpr int plan_lp_rows(int N) { return 128 / plan_T(N) > 0 ? 128 / plan_T(N) : 1; }
 constexpr int plan_lp_threads(int N) { return plan_lp_rows(N) * kLayers * plan_T(N); }
 constexpr int plan_lp_lds_cplx(int N) { return plan_region_cplx(N) * plan_lp_rows(N) * kLayers + plan_tw_total(N); }
+constexpr int plan_lp_handoff_cplx(int N) { return plan_lp_threads(N) / 2; }  // tick groups, pipelined pass 2: one half's foam values for the other
 
 // Work items of the tick-group kernel (k_tick_group_c_lp) for `slots` cascades.  Pass 2: one item = plan_lp_rows(N) rows.  Pass 1:
 // one item = one BLOCK of Q side-by-side 8-row sub-items, all of the same kind, so that the block barriers inside the layer path
@@ -551,6 +552,9 @@ struct TickPlan {
         row0 = (group % GPS) * kWgRows;
     }
     static constexpr int items_2(int slots) { return slots * (N / plan_lp_rows(N)); }
+    // the pipelined pass-2 form (TickGroupArgs::p2_pipe): a block = half as many columns, its two halves work on alternate ticks
+    static constexpr int kPipeRows = plan_lp_rows(N) / 2 > 0 ? plan_lp_rows(N) / 2 : 1;
+    static constexpr int items_2_pipe(int slots) { return slots * (N / kPipeRows); }
     // sub-item `sub` (0..Q-1) of pass-1 item `item`: which (layer / row-0 transform L, launch slot, first row); false = this
     // sub-block has nothing to do (only in the last row-0 item)
     static OW_HD bool decode(int item, int sub, int slots, int &L, int &slot, int &row0) {
@@ -589,6 +593,7 @@ struct TickGroupArgs {
     int32_t pair_compact;            // k_tick_pair_c instead: the compact family's bodies, one batch of each pass --
     int32_t first2, slots2;          //   pass 2 of launch slots first2 .. first2 + slots2 - 1 (scratch slots tbase2[0] ...; slots2 = 0: none)
     int32_t first1, slots1;          //   pass 1 of launch slots first1 .. first1 + slots1 - 1 (scratch slots tbase1[0] ..., times time1[0][slot])
+    int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };
 // fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch
@@ -1052,16 +1057,17 @@ struct Pass2 {
         // lane part of the mirrored address for the smallest mirrored y the lane needs (j = 15): (N - t) - 7 T
         const uint32_t voff_m = t_unit(N, 0, xp, N - t - 7 * T) * 8u;
         const float kyb = (float)t * dky;
+        // all sixteen loads first, the arithmetic after them: written as one loop the compiler has been seen to wait for each load in
+        // turn (sixteen dependent round trips) when this is inlined into the pipelined tick-group loop
+        cplx v[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            v[j] = j < P / 2 ? gload8<AUX>(T_c, voff, t_soff(1, rot(j))) : gload8<AUX>(T_c, voff_m, (t_unit(N, 1, 0, 0) + t_unit(N, 0, 0, T * (15 - j))) * 8u);
+        OW_SCHED_FENCE();
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const float sc = 1.0f - __builtin_fmaf((float)(T * (rot(j) - 8)), dky, kyb);  // 1 - ky(y_j)
-            if (j < P / 2) {
-                const cplx v = gload8<AUX>(T_c, voff, t_soff(1, rot(j)));
-                d[j] = cscale(v, sc);
-            } else {
-                const cplx v = gload8<AUX>(T_c, voff_m, (t_unit(N, 1, 0, 0) + t_unit(N, 0, 0, T * (15 - j))) * 8u);
-                d[j] = cplx{v.x * sc, v.y * -sc};
-            }
+            d[j] = j < P / 2 ? cscale(v[j], sc) : cplx{v[j].x * sc, v[j].y * -sc};
         }
     }
     static OW_DEV void put_row0(cplx *d, int t, cplx r) {

@@ -117,14 +117,19 @@ template <int N, bool F32>
 static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     using TP = TickPlan<N>;
     if (g.pair_compact) return launch_pair_n<N, F32>(args, g, buf, s, lt);
-    g.n2 = g.d2 > 0 ? TP::items_2(g.slots) : 0;
+    if (plan_lp_rows(N) < 2) g.p2_pipe = 0;
+    g.n2 = g.d2 > 0 ? (g.p2_pipe ? TP::items_2_pipe(g.slots) : TP::items_2(g.slots)) : 0;
     g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;
     if (blocks < 1) return hipErrorInvalidValue;
-    launch(k_tick_group_c_lp<N, F32>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g);
+    if (g.p2_pipe) launch(k_tick_group_c_lp<N, F32, false, true>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
+    else launch(k_tick_group_c_lp<N, F32>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
     return hipGetLastError();
 }
 bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+int tick_group_pipe_blocks(int n, int slots) {
+    return n == 256 ? TickPlan<256>::items_2_pipe(slots) : n == 512 ? TickPlan<512>::items_2_pipe(slots) : n == 1024 ? TickPlan<1024>::items_2_pipe(slots) : 0;
+}
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
 #define OW_GROUP(NN) \

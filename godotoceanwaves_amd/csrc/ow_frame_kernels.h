@@ -1152,24 +1152,24 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass1c_lp(DeviceBuffe
 // tau = thread index inside the item's plan_lp_threads(N) lanes; rows_lds = the item's plan_lp_rows(N) x 4 row regions
 // foam: the lane's four FP16 foam values (8 bytes).  foam_io & 1: load them from the foam plane first; & 2: store them back at the end
 // (a caller that runs consecutive ticks of the same rows keeps them in registers in between)
-template <int N, bool F32, int AUX_T, int AUX_O, class Issued, class WS>
-__device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds,
-                                               cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws, cplx &foam_bits, int foam_io = 3) {
-    constexpr int Tn = plan_T(N), P = kP, ROWS = plan_lp_rows(N), PER_LAYER = ROWS * Tn;
+// The layer-parallel pass 2 of RH consecutive columns in two halves, as functions of the lane index tau (0 .. 4 RH N/16 - 1):
+//   front: the lane group's transform -- loads (+ the lane's foam values when foam_load), row IFFT, results staged in `regions`
+//   back : (after a block barrier) all four transforms of a texel from `regions` -> unpack, map stores; foam_bits in -> out
+// pass2c_lp_item below runs them back to back; the pipelined tick groups run front(tick j + 1) beside back(tick j).
+template <int N, int RH, int AUX_T, class Issued, class WS>
+__device__ __forceinline__ void pass2c_lp_front(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds, cplx *regions,
+                                                RowSync<N> &rs, Issued issued, WS &ws, cplx &foam_bits, bool foam_load) {
+    constexpr int Tn = plan_T(N), P = kP, PER_LAYER = RH * Tn;
     const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);  // which of F0..F3 this lane group transforms (wave-uniform)
     const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     const int xp = row0 + r;
-    const uint32_t tex = (uint32_t)(xp * N + t);
     const GBuf T_c = make_gbuf(buf.T + (size_t)tslot * plane * kLayers, t_cascade_bytes(N));
     const GBuf pcol_c = make_gbuf(buf.pcol + (size_t)tslot * N, (uint32_t)N * 8u);
     const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
-    const GBuf disp_c = make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u);
-    const GBuf norm_c = make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u);
     const GBuf foam_c = make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u);
-    const GBuf f32_c = make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u);
     const float dky = (2.0f * kPi) / cf.tile_y;
-    auto region = [&](int row, int layer) { return rows_lds + (layer * ROWS + row) * plan_region_cplx(N); };
+    cplx *mine = regions + (g * RH + r) * plan_region_cplx(N);
 
     cplx d[P];
     switch (g) {  // group-uniform
@@ -1182,20 +1182,37 @@ __device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const C
         default: Pass2<N>::template load_layer<AUX_T>(d, t, xp, 2, T_c); break;
     }
     if (g != 0) Pass2<N>::put_row0(d, t, gload8<AUX_T>(rrow_c, (uint32_t)xp * 32u, (uint32_t)g * 8u));
-    if (foam_io & 1) foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
+    if (foam_load) foam_bits = gload8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u);
     ws.at(1, 0.0f);                     // loads issued
     issued();
     ws.at(3, d[15].x + foam_bits.x);    // the wave's own data has arrived
-    row_ifft<N>(d, t, region(r, g), tw_lds, rs);
+    row_ifft<N>(d, t, mine, tw_lds, rs);
     ws.at(6, d[15].x);                  // transformed
     rs.sync();
-    {
-        cplx *mine = region(r, g);
 #pragma unroll
-        for (int o = 0; o < P; ++o) mine[t + Tn * o] = d[OutMap<N>::slot_of(o)];
-    }
-    lds_barrier();
-    ws.at(7, 0.0f);                     // all four transforms of the row are in LDS
+    for (int o = 0; o < P; ++o) mine[t + Tn * o] = d[OutMap<N>::slot_of(o)];
+}
+// the output side of one cascade (built once per block: the scalar loads and address arithmetic behind them stay off the per-tick path)
+struct P2Out {
+    GBuf disp_c, norm_c, foam_c, f32_c;
+};
+template <int N, bool F32>
+__device__ __forceinline__ P2Out make_p2_out(const DeviceBuffers &buf, const CascadeFrame &cf) {
+    const uint32_t plane = (uint32_t)N * N;
+    return P2Out{make_gbuf(buf.disp + (size_t)cf.cascade * plane, plane * 8u), make_gbuf(buf.norm + (size_t)cf.cascade * plane, plane * 8u),
+                 make_gbuf(buf.foam + (size_t)cf.cascade * plane, plane * 2u),
+                 make_gbuf(F32 ? buf.f32 + (size_t)cf.cascade * plane * 8 : nullptr, F32 ? plane * 32u : 0u)};
+}
+template <int N, bool F32, int RH, int AUX_O, class WS>
+__device__ __forceinline__ void pass2c_lp_back(const P2Out &out, const CascadeFrame &cf, int row0, int tau, const cplx *regions, WS &ws, cplx &foam_bits,
+                                               bool foam_store) {
+    constexpr int Tn = plan_T(N), PER_LAYER = RH * Tn;
+    const int g = __builtin_amdgcn_readfirstlane(tau / PER_LAYER);
+    const int r = (tau % PER_LAYER) / Tn, t = tau % Tn;
+    const int xp = row0 + r;
+    const uint32_t tex = (uint32_t)(xp * N + t);
+    const GBuf disp_c = out.disp_c, norm_c = out.norm_c, foam_c = out.foam_c, f32_c = out.f32_c;
+    auto region = [&](int row, int layer) { return regions + (layer * RH + row) * plan_region_cplx(N); };
     const float fb0 = foam_bits.x, fb1 = foam_bits.y;
     const uint32_t fpk[2] = {__builtin_bit_cast(uint32_t, fb0), __builtin_bit_cast(uint32_t, fb1)};
     uint32_t fnew[2] = {0u, 0u};
@@ -1212,8 +1229,18 @@ __device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const C
     }
     const float fn0 = __builtin_bit_cast(float, fnew[0]), fn1 = __builtin_bit_cast(float, fnew[1]);
     foam_bits = cplx{fn0, fn1};
-    if (foam_io & 2) gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, foam_bits);
+    if (foam_store) gstore8(foam_c, Pass2<N>::foam_index(xp, t) * 2u, (uint32_t)g * 8u, foam_bits);
     ws.at(8, 0.0f);                     // unpacked, stores issued
+}
+template <int N, bool F32, int AUX_T, int AUX_O, class Issued, class WS>
+__device__ __forceinline__ void pass2c_lp_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds,
+                                               cplx *rows_lds, RowSync<N> &rs, Issued issued, WS &ws, cplx &foam_bits, int foam_io = 3) {
+    constexpr int ROWS = plan_lp_rows(N);
+    const P2Out out = make_p2_out<N, F32>(buf, cf);  // (before the loads: its scalar work runs under their latency)
+    pass2c_lp_front<N, ROWS, AUX_T>(buf, cf, tslot, row0, tau, tw_lds, rows_lds, rs, issued, ws, foam_bits, (foam_io & 1) != 0);
+    lds_barrier();
+    ws.at(7, 0.0f);                     // all four transforms of the row are in LDS
+    pass2c_lp_back<N, F32, ROWS, AUX_O>(out, cf, row0, tau, rows_lds, ws, foam_bits, (foam_io & 2) != 0);
 }
 
 template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault, bool STAMPS = false>
@@ -1261,25 +1288,63 @@ __global__ __launch_bounds__(plan_lp_threads(N), 2) void k_pass2c_lp(DeviceBuffe
 // side-by-side 8-row items per block -- all of the same layer in the layer-parallel form, each doing all its layers in k_pass1c's
 // form, g.p1_compact, which the runtime picks for all but the smallest ticks); d2 or d1 may be 0 (the two ends of a run).
 // ===================================================================================================
-template <int N, bool F32>
-__global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
+template <int N, bool F32, bool STAMPS = false, bool PIPE = false>
+__global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(DeviceBuffers buf, FrameArgs args, TickGroupArgs g, Stamp *stamps = nullptr) {
     using TP = TickPlan<N>;
     constexpr int ROWS = plan_lp_rows(N), SUB = plan_wg_threads(N);
     static_assert(!plan_row_spans_waves(N), "small-batch sizes only (N <= 1024)");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N)];
+    __shared__ __attribute__((aligned(16))) cplx lds[plan_lp_lds_cplx(N) + (PIPE ? plan_lp_handoff_cplx(N) : 0)];
     cplx *tw_lds = lds;
     cplx *rows_lds = lds + plan_tw_total(N);
     RowSync<N> rs;
     NoStamps ws;
+    WaveStamps<STAMPS> tl;  // developer timeline (tools/kbench_small): pass 2 -- [j] = start of tick j, [d2] = end; pass 1 -- [0], [1]
+    tl.at(0, 0.0f);
     TwPrefetch<N> twp;
     tw_fetch<N>(twp, buf.tw);
-    if ((int)blockIdx.x < g.n2) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
+    // (PIPE is its own instantiation, not a run-time branch: with one wave per SIMD the instruction stream of a small launch is
+    //  latency bound, and the second copy of the pass-2 code in the kernel cost the plain form 1.5 us per tick at 256^2)
+    if constexpr (PIPE && ROWS >= 2) {
+        if ((int)blockIdx.x < g.n2) {
+            // ---- pass 2, pipelined: the block's two halves (4 lane groups x RH columns each) take alternate ticks of the same RH columns.
+            // In step s one half runs the FRONT of tick s (loads, transform, results staged in its own regions) while the other runs
+            // the BACK of tick s - 1 (unpack from its regions, map stores); the foam values -- all that one tick hands to the next --
+            // cross from half to half through LDS.  A tick then costs max(front, back) on the chain of ticks instead of their sum:
+            // with one wave per SIMD (a 256^2 x 4 launch has 1024 pass-2 waves) that chain IS the launch.
+            constexpr int RH = TP::kPipeRows, HALF = plan_lp_threads(N) / 2;
+            const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / HALF);
+            const int item = blockIdx.x, slot = item / (N / RH), row0 = (item % (N / RH)) * RH;
+            const CascadeFrame cf = args.c[slot];
+            fetch_arguments(buf, cf);
+            cplx *regions = rows_lds + half * (kLayers * RH) * plan_region_cplx(N);
+            cplx *handoff = lds + plan_lp_lds_cplx(N);
+            const P2Out out = make_p2_out<N, F32>(buf, cf);
+            tw_commit<N>(twp, tw_lds);
+            cplx foam_bits = cplx{0.0f, 0.0f};
+            for (int s = 0; s <= g.d2; ++s) {
+                const int tau = opaque((int)threadIdx.x % HALF);
+                if (s < g.d2 && (s & 1) == half)
+                    pass2c_lp_front<N, RH, kAuxDefault>(buf, cf, g.tbase2[s] + slot, row0, tau, tw_lds, regions, rs, [] {}, ws, foam_bits, s == 0);
+                if (s >= 1 && ((s - 1) & 1) == half) {
+                    if (s > 1) foam_bits = lds_read(handoff + tau);  // (written by the other half one step ago)
+                    pass2c_lp_back<N, F32, RH, kAuxDefault>(out, cf, row0, tau, regions, ws, foam_bits, s == g.d2);
+                    handoff[tau] = foam_bits;
+                }
+                lds_barrier();
+                if (s + 1 <= 13) tl.at(s + 1, foam_bits.x);
+            }
+            tl.write(stamps, plan_lp_threads(N) / 64, 0ull);
+            return;
+        }
+    }
+    if (!PIPE && (int)blockIdx.x < g.n2) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
         const int item = blockIdx.x;
         const int slot = item / (N / ROWS), row0 = (item % (N / ROWS)) * ROWS;
         const CascadeFrame cf = args.c[slot];  // (pass 2 does not use the time)
         fetch_arguments(buf, cf);
         cplx foam_bits;
         for (int j = 0; j < g.d2; ++j) {
+            if (j > 0) tl.at(j, foam_bits.x);
             const int tau = opaque((int)threadIdx.x);  // per tick: lane-derived offsets are recomputed, not carried around the loop
             const int io = (j == 0 ? 1 : 0) | (j == g.d2 - 1 ? 2 : 0);
             if (j == 0) {
@@ -1290,6 +1355,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
                 pass2c_lp_item<N, F32, kAuxDefault, kAuxDefault>(buf, cf, g.tbase2[j] + slot, row0, tau, tw_lds, rows_lds, rs, [] {}, ws, foam_bits, io);
             }
         }
+        tl.at(g.d2 < 13 ? g.d2 : 13, foam_bits.x);
+        tl.write(stamps, plan_lp_threads(N) / 64, 0ull);
         return;
     }
     // ---- pass 1: tick j of the later group ----
@@ -1303,6 +1370,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
         fetch_arguments(buf, cf);
         pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[j][slot], g.tbase1[j] + slot, row0, tau_sub, tw_lds,
                                                  rows_lds + sub * kWgRows * plan_region_cplx(N), rs, [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
+        tl.at(1, 0.0f);
+        tl.write(stamps, plan_lp_threads(N) / 64, 1000ull + (unsigned long long)j);
         return;
     }
     // Q items of one layer side by side (the layer-parallel form)
@@ -1318,6 +1387,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
     } else {
         tw_commit<N>(twp, tw_lds);
     }
+    tl.at(1, 0.0f);
+    tl.write(stamps, plan_lp_threads(N) / 64, 1000ull + (unsigned long long)j);
 }
 
 // TICK PAIRS on the compact family (ow_run on the batches that family serves): the ticks of a run are a stream of batches of at

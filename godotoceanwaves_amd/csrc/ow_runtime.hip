@@ -67,7 +67,7 @@ struct ow_context {
     uint32_t inject_fault = 0;  // ow_debug_inject_fault: applied to the next batch only
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
-    int group_p1_form = -1;
+    int group_p1_form = -1, group_p2_form = -1;
     int group_max_count = 0, group_depth = 0;
     // ow_run's tick pairs on the compact family (k_tick_pair_c): the largest batch they launch (0 = never); scratch two batches deep
     int pair_slots = 0;
@@ -164,6 +164,8 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     // measurement knob (scripts/group_p1_body.py): force one pass-1 item form in the tick groups; -1 = the runtime's own choice
     c->group_p1_form = -1;
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
+    c->group_p2_form = -1;
+    if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P2")) c->group_p2_form = strcmp(e, "pipe") == 0 ? 1 : strcmp(e, "plain") == 0 ? 0 : -1;
 }
 int scratch_slots(const ow_context *c) {
     return std::max({std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count, 2 * c->pair_slots});
@@ -630,6 +632,14 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
     // per tick lp / compact: 256^2 x 1 4.40 / 4.50, x 4 5.02 / 5.05, x 5 6.01 / 6.28, x 6 7.06 / 6.70, x 8 9.55 / 7.77;
     // 512^2 x 1 7.25 / 7.04, x 2 10.1 / 8.5, x 4 19.4 / 15.2, x 6 31.4 / 28.1; 1024^2 x 1 19.0 / 15.8   (scripts/group_p1_body.py)
     ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
+    // pass-2 blocks: the pipelined form (k_tick_group_c_lp<.., PIPE>: a block's two halves on alternate ticks) while its blocks are at most
+    // one per CU -- there a launch lasts as long as the chain of ticks through one wave, and the chain is what the pipeline shortens;
+    // with it the pass-1 items take k_pass1c's form (fewer blocks beside the resident pass-2 blocks).  Measured, MI355X, us per tick
+    // plain / pipelined (scripts/group_p2_form.py): 256^2 x 1 4.32 / 2.96, x 2 4.45 / 3.04, x 4 4.84 / 3.70, x 8 7.56 / 9.14;
+    // 512^2 x 1 5.86 / 5.47, x 2 7.74 / 9.97, x 4 14.2 / 14.5
+    const bool pipe_fits = ow::tick_group_pipe_blocks(c->n, count) > 0 && ow::tick_group_pipe_blocks(c->n, count) <= 256;
+    ga.p2_pipe = c->group_p2_form >= 0 ? c->group_p2_form : pipe_fits;
+    if (ga.p2_pipe && c->group_p1_form < 0) ga.p1_compact = 1;
     // pass 1 of group 0
     ga.d2 = 0;
     ga.d1 = group_size(0);

@@ -98,8 +98,9 @@ typedef struct ow_config {
  *    texels and one launch does pass 2 of one batch and pass 1 of the next -- the same cascades one tick later, or the tick's other
  *    cascades (k_tick_pair_c).
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
- * (Measurement knob, read by ow_create: the environment variable OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" forces one of the two forms of
- * the groups' pass-1 work items; unset, the runtime picks by batch size.  Results do not depend on it.) */
+ * (Measurement knobs, read by ow_create: the environment variables OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" and OW_DEBUG_TICK_GROUP_P2 =
+ * "plain" | "pipe" force one of the two forms of the groups' pass-1 / pass-2 work items; unset, the runtime picks by batch size.  Results
+ * do not depend on them.) */
 #define OW_FLAG_NO_TICK_GROUPS 16u
 
 typedef struct ow_context ow_context;

@@ -31,16 +31,19 @@ def same_maps(a, b, count):
         assert np.array_equal(na.view(np.uint16), nb.view(np.uint16)), i
 
 
-@pytest.mark.parametrize("p1_form", [None, "lp", "compact"])
+@pytest.mark.parametrize("forms", [(None, None), ("lp", "plain"), ("compact", "plain"), ("lp", "pipe"), ("compact", "pipe")], ids=lambda f: f"p1_{f[0]}-p2_{f[1]}")
 @pytest.mark.parametrize("n,ids", [(256, [0, 1, 2, 3]), (256, [0, 1, 2, 3, 4, 5, 6, 7]), (512, [2]), (512, [0, 1, 2, 3]), (1024, [1])])
 @pytest.mark.parametrize("frames", [2, 3, 4, 17, 40])
-def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, p1_form, monkeypatch):
-    """p1_form: the runtime picks the pass-1 item form by batch size (layer-parallel items for 256^2 maps below 384 Ki texels per tick,
-    k_pass1c-shaped 8-row items otherwise); both forms are held to the same bits at every size (OW_DEBUG_TICK_GROUP_P1, read by ow_create)."""
-    if p1_form:
-        monkeypatch.setenv("OW_DEBUG_TICK_GROUP_P1", p1_form)
-    else:
-        monkeypatch.delenv("OW_DEBUG_TICK_GROUP_P1", raising=False)
+def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, forms, monkeypatch):
+    """The runtime picks the form of the groups' work items by batch size -- pass 1: layer-parallel items or k_pass1c-shaped 8-row items;
+    pass 2: plain blocks (a block walks through the ticks of its columns) or pipelined ones (the block's two halves on alternate ticks,
+    foam handed over through LDS; blocks at most one per CU).  Every combination is held to the same bits at every size
+    (OW_DEBUG_TICK_GROUP_P1 / _P2, read by ow_create; (None, None) = the runtime's own choice)."""
+    for var, form in zip(("OW_DEBUG_TICK_GROUP_P1", "OW_DEBUG_TICK_GROUP_P2"), forms):
+        if form:
+            monkeypatch.setenv(var, form)
+        else:
+            monkeypatch.delenv(var, raising=False)
     a, pa = make(n, ids, True)
     b, pb = make(n, ids, False)
     a.run(UPDATE_DELTA, pa, frames)

@@ -197,5 +197,77 @@ int main(int argc, char **argv) {
                                  "all four transforms in LDS (block barrier)", "unpacked, stores issued", "", "", "", "", "", "stores acknowledged"};
         report("k_pass2c_lp", h, names, 15, t2);
     }
+    {   // ---- tick groups (k_tick_group_c_lp): duration of a full launch (pass 2 of D ticks + pass 1 of the next D) and where its waves spend it ----
+        //   kbench_small_<N> C iters [D [pass-1 items: 0 layer-parallel, 1 compact [pass 2: 0 plain, 1 pipelined]]]
+        using TP = TickPlan<N>;
+        const int D = argc > 3 ? atoi(argv[3]) : 8, p1c = argc > 4 ? atoi(argv[4]) : 0, pipe = argc > 5 ? atoi(argv[5]) : 0;
+        DeviceBuffers gb = buf;
+        CK(hipMalloc((void **)&gb.T, (size_t)2 * D * L * pl * 32));
+        CK(hipMemset(gb.T, 0, (size_t)2 * D * L * pl * 32));
+        CK(hipMalloc((void **)&gb.pcol, (size_t)2 * D * C * N * 8));
+        CK(hipMalloc((void **)&gb.rrow, (size_t)2 * D * C * N * 32));
+        CK(hipMemset(gb.pcol, 0, (size_t)2 * D * C * N * 8));
+        CK(hipMemset(gb.rrow, 0, (size_t)2 * D * C * N * 32));
+        TickGroupArgs ga{};
+        ga.slots = C;
+        ga.p1_compact = p1c;
+        ga.p2_pipe = pipe;
+        ga.d2 = ga.d1 = D;
+        ga.n2 = pipe ? TP::items_2_pipe(C) : TP::items_2(C);
+        ga.n1 = p1c ? TP::items_1_compact(C) : TP::items_1(C);
+        int parity = 0;
+        auto fill = [&] {
+            for (int j = 0; j < D; ++j) {
+                ga.tbase2[j] = (parity * D + j) * C;
+                ga.tbase1[j] = ((parity ^ 1) * D + j) * C;
+                for (int i = 0; i < C; ++i) ga.time1[j][i] = 120.5f + i + 0.02f * j;
+            }
+            parity ^= 1;
+        };
+        const int blocks = ga.n2 + D * ga.n1, wpb = plan_lp_threads(N) / 64;
+        auto launch = [&](bool stamped, Stamp *out) {
+            const dim3 gr(blocks), bl(plan_lp_threads(N));
+            if (pipe) {
+                if (stamped) hipLaunchKernelGGL((k_tick_group_c_lp<N, false, true, true>), gr, bl, 0, s, gb, args, ga, out);
+                else hipLaunchKernelGGL((k_tick_group_c_lp<N, false, false, true>), gr, bl, 0, s, gb, args, ga, out);
+            } else {
+                if (stamped) hipLaunchKernelGGL((k_tick_group_c_lp<N, false, true, false>), gr, bl, 0, s, gb, args, ga, out);
+                else hipLaunchKernelGGL((k_tick_group_c_lp<N, false, false, false>), gr, bl, 0, s, gb, args, ga, out);
+            }
+        };
+        auto grp = [&] { fill(); launch(false, nullptr); };
+        const float tg = time_it(grp, std::max(50, iters / D), s);
+        printf("tick group: D = %d, pass-1 items %s, pass 2 %s: %d pass-2 blocks + %d x %d pass-1 blocks of %d threads: %7.2f us per launch = %6.2f us per tick\n", D,
+               p1c ? "compact" : "layer-parallel", pipe ? "pipelined" : "plain", ga.n2, D, ga.n1, plan_lp_threads(N), tg, tg / D);
+        Stamp *gs;
+        CK(hipMalloc(&gs, sizeof(Stamp) * (size_t)blocks * wpb));
+        CK(hipMemset(gs, 0, sizeof(Stamp) * (size_t)blocks * wpb));
+        for (int i = 0; i < 20; ++i) grp();
+        fill();
+        launch(true, gs);
+        CK(hipStreamSynchronize(s));
+        std::vector<Stamp> h((size_t)blocks * wpb);
+        CK(hipMemcpy(h.data(), gs, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        // per-wave differences only (the counters of different XCDs are not comparable).  Pass-2 waves live through the whole launch:
+        // their average life calibrates ticks per us.  Stamps: [k] = start of tick k (plain) / end of step k - 1 (pipelined), k >= 1.
+        const int steps = pipe ? D + 1 : D;
+        double p2_life = 0, p2_step[16] = {0}, p1_life = 0;
+        int n2w = 0, n1w = 0;
+        for (auto &x : h) {
+            if (!x.t[0]) continue;
+            if (x.t[15] < 1000) {
+                ++n2w;
+                p2_life += (double)(x.t[14] - x.t[0]);
+                for (int j = 0; j < steps && j < 13; ++j) p2_step[j] += (double)(x.t[j + 1] - x.t[j]);
+            } else {
+                ++n1w;
+                p1_life += (double)(x.t[14] - x.t[0]);
+            }
+        }
+        const double per_us = p2_life / n2w / tg;
+        printf("  pass-2 waves (%d) live %.0f ticks = the launch (=> %.0f ticks per us); per %s:", n2w, p2_life / n2w, per_us, pipe ? "step" : "tick");
+        for (int j = 0; j < steps && j < 13; ++j) printf(" %.2f", p2_step[j] / n2w / per_us);
+        printf(" us\n  pass-1 waves (%d): average life %.2f us\n", n1w, p1_life / n1w / per_us);
+    }
     return 0;
 }
