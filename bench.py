@@ -244,22 +244,25 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     grouped = merged
     if grouped:
         # ow_run launched the timed ticks merged across ticks -- tick groups (k_tick_group_c_lp: pass 2 of GROUP ticks + pass 1 of the next
-        # GROUP per launch) or tick pairs (k_tick_pair_c: pass 2 of one tick + pass 1 of the next, GROUP = 1): that kernel dominates the
-        # timed region.  Its launches were timed one by one (HIP events on each dispatch, timing mode 2) over `probe` further ticks, of
-        # which the first takes the ordinary path: T = probe - 1 ticks in ceil(T / GROUP) + 1 launches (the first carries pass 1
-        # only, the last pass 2 only).  achieved = all bytes those launches move / the sum of their durations.
+        # GROUP per launch) or tick pairs (k_tick_pair_c: pass 2 of one batch + pass 1 of the next, GROUP = 1): that kernel IS the timed
+        # region -- K ticks are K * batches / GROUP launches of it back to back on one in-order stream (+ one: the two ends of a run carry
+        # one pass each) -- so its average launch duration is the timed region divided by its launches, and that is the figure the
+        # rocprofv3 kernel trace of the same command lists (closing visit of round 2: 52.48 us here, 52.41 us in the trace).
+        # The same launches timed one by one with a pair of HIP events each (timing mode 2, `probe` further ticks) are reported beside it
+        # (avg_launch_ms_events): those brackets include the event packets' own handling and scatter by +-5 % from visit to visit.
         # (p1 / p2 below are the one-launch-per-pass kernels of the same tick, probed after.)
         GROUP = max(1, group_depth)
-        dom, dom_ms = MERGED_KERNEL[launch_mode], gl_ms
+        dom = MERGED_KERNEL[launch_mode]
         # (foam is read before the first and written after the last of a group's ticks only: 4 B/texel less for each tick in between)
         T = probe - 1
         groups = -(-T // GROUP)
         batches = max(1, round((gl_n - 1) / groups))   # tick pairs: a tick of more than 4 Mi texels is two batches, one launch each
         per_launch = C // batches if C % batches == 0 else round(C / batches, 3)
         dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C / batches
-        total_bytes = ((k1 + k2) * T - 4 * (T - groups)) * n * n * C
-        achieved = gbps(total_bytes, gl_ms * gl_n)
-        contract = gbps(sum(CONTRACT_BYTES) * T * n * n * C, gl_ms * gl_n)
+        dom_ms = elapsed / args.steps * 1e3 * GROUP / batches          # time per tick x ticks per launch
+        achieved = gbps(dom_bpt * texels, dom_ms)
+        contract = gbps(dom_contract * texels, dom_ms)
+        events_achieved = gbps(((k1 + k2) * T - 4 * (T - groups)) * n * n * C, gl_ms * gl_n)
     else:
         achieved = gbps(dom_bpt * texels, dom_ms)
         contract = gbps(dom_contract * texels, dom_ms)
@@ -304,8 +307,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "bytes_per_texel": dom_bpt, "bytes_per_launch": int(dom_bpt * texels),
             "bytes_basis": "bytes the launched kernel family must move (bench.py FAMILY_BYTES, DESIGN.md section 3)" +
-                           (f"; one launch = both passes of {max(1, group_depth)} tick(s); achieved = all bytes of the {gl_n} launches timed one by one / the sum of their durations "
-                            "(the first and last launch of a run carry one pass only)" if grouped else ""),
+                           (f"; one launch = both passes of {max(1, group_depth)} tick(s) of {per_launch} cascade(s); its average duration = the timed region / its launches "
+                            "(back to back on one in-order stream)" if grouped else ""),
             "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBPS, 4), "copy_ceiling": COPY_CEILING_GBPS,
             # SURVEY 8d's contract bytes (four-layer FP32 intermediate, 104 B/texel per map) over the same duration: a
             # figure of merit against a design that moves more, NOT a bandwidth (it can exceed the copy ceiling)
@@ -314,6 +317,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of an earlier visit, NOT measured by this run" if traffic else None,
             "traffic_gbps": round(gbps(traffic, dom_ms), 1) if traffic else None,
             "avg_launch_ms": round(dom_ms, 5), "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5),
+            **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n} if grouped else {}),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
             "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
