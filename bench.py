@@ -10,9 +10,15 @@
            sides, max over ranks.  The region is repeated (`repeats`) until at least --min-time seconds have been
            timed; `ms_per_step` / `value` are the MEDIAN repeat (a 20-tick region is 1 ms: one sample of it is noise)
   N > 1  : cascades/tiles are independent units: every rank owns its own C cascades (weak scaling,
-           no data-path collective).  The finished maps are gathered over RCCL by sharding.MapGatherer: owned layers
-           only, from a snapshot, on a side stream -- once after the timed region ("final gather"), or every k ticks
-           inside it with --gather-every k (then the rate without any gather is measured and reported beside it).
+           no data-path collective).  The default shape is BASELINE config C4: ONE 1024^2 cascade per GPU, finished maps
+           gathered to rank 0 (the consumer GPU) over RCCL by sharding.MapGatherer -- owned layers only, from a snapshot,
+           on a side stream -- INSIDE the timed region, every k ticks, k = the smallest cadence whose gather hides under
+           k ticks of compute (measured during warm-up, agreed over ranks; --gather-every k pins it, 0 = once after the
+           region).  `value` is that region; `no_gather` (no exchange at all) and `gather_every_tick` (k = 1: the
+           link-bound rate of a consumer that wants every tick) are timed the same way and reported beside it.
+  N = 1  : `roofline.unmerged` times the same ticks with one launch per pass (OW_FLAG_NO_TICK_GROUPS: what ow_update_all /
+           ow_process callers get, no look-ahead across ticks), `roofline.residency` says what of the working set fits the
+           256 MiB Infinity Cache (so a reader knows when "HBM GB/s" is partly cache traffic).
   sweep  : --sweep appends one line per BASELINE configuration (256^2 x 4, 1024^2 x {1,4,8}, 2048^2 x 4), each with its
            own roofline and CPU baseline, to --sweep-out (profiles/) and prints the headline line last.
 
@@ -54,11 +60,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--map-size", type=int, default=1024)
-    ap.add_argument("--cascades", type=int, default=4, help="cascades per GPU")
+    ap.add_argument("--cascades", type=int, default=None, help="cascades per GPU (default: 4 at --gpus 1 = the headline config; 1 at --gpus N > 1 = BASELINE config C4)")
     ap.add_argument("--min-time", type=float, default=0.5, help="repeat the K-tick timed region until this many seconds have been timed (median reported)")
     ap.add_argument("--max-repeats", type=int, default=500)
-    ap.add_argument("--gather-every", type=int, default=0, help="gather the maps every k ticks inside the timed region (0 = once, after it)")
-    ap.add_argument("--gather", choices=("all", "root"), default="all", help="all_gather to every rank, or gather to rank 0 (the consumer GPU)")
+    ap.add_argument("--gather-every", type=int, default=-1, help="gather the maps every k ticks inside the timed region (0 = once, after it; "
+                                                                   "-1 = auto: the smallest k whose gather hides under k ticks of compute)")
+    ap.add_argument("--gather", choices=("all", "root"), default="root", help="gather to rank 0 (the consumer GPU), or all_gather to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="serialise each gather with the compute stream (for comparison; default: side stream)")
     ap.add_argument("--prime-ms", type=float, default=300.0,
                     help="untimed clock priming before the W warm-up steps: the chip's DVFS needs tens of ms of load to reach its "
@@ -67,6 +74,7 @@ def parse():
                                                      "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (numbers are meaningless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unmerged", action="store_true", help="skip the second timed region (one launch per pass) behind roofline.unmerged")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample size in seconds of host work")
     ap.add_argument("--sweep", action="store_true", help="one line per BASELINE configuration, appended to --sweep-out")
     ap.add_argument("--sweep-out", default=os.path.join(ROOT, "profiles", "sweep.jsonl"))
@@ -119,12 +127,16 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     disp = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
     norm = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
     torch.cuda.synchronize()
-    gen = WaveGenerator()
-    gen.map_size = n
-    gen.device_id = local_rank
-    gen.stream = compute.cuda_stream
-    gen.external_maps = (disp.data_ptr(), norm.data_ptr())
-    gen.init_gpu(layers)
+    def make_generator(tick_groups=True):
+        g = WaveGenerator()
+        g.map_size = n
+        g.device_id = local_rank
+        g.stream = compute.cuda_stream
+        g.tick_groups = tick_groups
+        g.external_maps = (disp.data_ptr(), norm.data_ptr())
+        g.init_gpu(layers)
+        return g
+    gen = make_generator()
     # global cascade ids: rank r owns cascades r*C .. r*C+C-1 (independent units; presets repeat with new seeds)
     params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
     gat = None
@@ -184,13 +196,34 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         gat.begin()
         gat.wait()
 
+    # ---- gather cadence (N > 1): the smallest k whose gather hides under k ticks of compute, from two short probes ----
+    gather_every, cadence = 0, None
+    if world > 1:
+        gather_every = args.gather_every
+        if gather_every < 0:
+            sync_all()
+            t0 = time.perf_counter()
+            gen.run(UPDATE_DELTA, params, 200)
+            sync_all()
+            tick_probe = max_over_ranks(time.perf_counter() - t0) / 200
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gat.begin()
+                gat.wait()
+            sync_all()
+            gather_probe = max_over_ranks(time.perf_counter() - t0) / 5
+            gather_every = max(1, int(math.ceil(1.25 * gather_probe / max(tick_probe, 1e-9))))  # 25 % slack: the links must never be the queue
+            cadence = {"policy": "auto: smallest k with 1.25 x gather time <= k ticks", "tick_probe_ms": round(tick_probe * 1e3, 5),
+                       "gather_probe_ms": round(gather_probe * 1e3, 4)}
+
     # ---- timed regions ----
-    elapsed, samples = timed(args.gather_every if world > 1 else 0)
+    elapsed, samples = timed(gather_every)
     group_depth = gen.tick_group_depth()
     launch_mode = gen.last_kernel_family()  # "tick_groups_compact": ow_run launched pass 2 of tick k with pass 1 of tick k + 1 (small batches)
-    no_gather = None
-    if world > 1 and args.gather_every > 0:
+    no_gather = every_tick = None
+    if world > 1 and gather_every > 0:
         no_gather, _ = timed(0)
+        every_tick = elapsed if gather_every == 1 else timed(1)[0]
 
     # ---- final gather (outside the timed region unless --gather-every) + sanity ----
     gather_ms = None
@@ -225,6 +258,17 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     family = gen.last_kernel_family()
     sync_all()
     gen.free()
+    # ---- the same ticks with ONE LAUNCH PER PASS (OW_FLAG_NO_TICK_GROUPS): what a caller of ow_update_all / ow_process gets -- the
+    #      reference's own schedule has no look-ahead across ticks (wave_generator.gd:56-63) -- timed exactly like the region above ----
+    unmerged = None
+    if world == 1 and not args.no_unmerged:
+        gen = make_generator(tick_groups=False)
+        gen.update_all(UPDATE_DELTA, params)
+        gen.run(UPDATE_DELTA, params, max(50, args.warmup))
+        gen.sync()
+        unmerged, unmerged_samples = timed(0)
+        assert gen.last_kernel_family() == family, (gen.last_kernel_family(), family)
+        gen.free()
     if rank != 0:
         return None
 
@@ -271,10 +315,23 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     tick_moved = tick_bpt * n * n * C / tick_s / 1e9          # per GPU
     tick_contract = sum(CONTRACT_BYTES) * n * n * C / tick_s / 1e9
     traffic = pmc_traffic(dom, n, per_launch)  # (per FULL launch of the merged kernels)
+    # what the tick keeps alive between its uses, against the 256 MiB memory-side Infinity Cache: where it fits, the "HBM" rates below
+    # (and TCC_EA-side PMC traffic) are partly cache hits, not DRAM traffic (MI355X_MICROARCH.md, HBM section)
+    t_bpt = 32 if family in ("standard", "layer_parallel") else 20
+    in_flight = 2 if launch_mode == "tick_pairs_compact" else (2 * max(1, group_depth) if launch_mode == "tick_groups_compact" else 1)
+    batch_texels = n * n * (per_launch if not isinstance(per_launch, float) else math.ceil(per_launch))
+    res = {"spectra_bytes": 12 * n * n * C, "intermediate_bytes": int(t_bpt * batch_texels * in_flight), "intermediate_batches_in_flight": in_flight,
+           "foam_bytes": 2 * n * n * C, "maps_bytes": 16 * n * n * C, "infinity_cache_bytes": 256 << 20}
+    res["reused_bytes"] = res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"]
+    res["reused_fits_infinity_cache"] = res["reused_bytes"] <= res["infinity_cache_bytes"]
+    res["note"] = ("spectra, intermediate and foam are re-read every tick; the output maps are write-only streams (stored non-temporally). "
+                   "Where the re-read set fits the Infinity Cache the achieved rates are fabric-side (cache + DRAM), not DRAM-only, traffic.")
     headline = (n, C) == (1024, 4)
     out = {
-        "metric": "displacement+normal maps/sec, 1024^2 x 4 cascades; achieved HBM GB/s vs peak" if headline else
-                  f"displacement+normal maps/sec, {n}^2 x {C} cascades; achieved HBM GB/s vs peak",
+        "metric": "displacement+normal maps/sec, 1024^2 x 4 cascades; achieved HBM GB/s vs peak" if (headline and world == 1) else
+                  (f"displacement+normal maps/sec, {n}^2 x {C} cascades; achieved HBM GB/s vs peak" if world == 1 else
+                   f"displacement+normal maps/sec, {n}^2 x {C * world} cascades sharded {C} per GPU over {world} GPUs, maps gathered to the consumer GPU; "
+                   f"achieved HBM GB/s vs peak (per GPU)"),
         "value": round(maps / elapsed, 2),
         "unit": "maps/s",
         "n_gpus": world,
@@ -297,8 +354,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
                                 "tick pairs: pass 2 of one batch and pass 1 of the next (the same cascades one tick later, or the tick's other cascades) in one launch (k_tick_pair_c)") +
                                "; pass1_ms / pass2_ms below are those of the same ticks launched one pass at a time" if grouped
                                else "one pair of launches per batch and tick",
-                   "gather": (f"{args.gather}, every {args.gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
-                             if (world > 1 and args.gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
+                   "gather": (f"{args.gather}, every {gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
+                             if (world > 1 and gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
                    **({"rehearsal": f"backend={args.backend}, share_gpu={args.share_gpu}: NOT a measurement"}
                       if (args.share_gpu or (world > 1 and args.backend != "nccl")) else {})},
         "roofline": {
@@ -319,6 +376,18 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             "avg_launch_ms": round(dom_ms, 5), "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5),
             **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n} if grouped else {}),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
+            "residency": res,
+            **({"unmerged": {"launches": "one launch per pass and batch (OW_FLAG_NO_TICK_GROUPS): what ow_update_all / ow_process callers get",
+                             "ms_per_step": round(unmerged / args.steps * 1e3, 5), "value": round(maps / unmerged, 2), "unit": "maps/s",
+                             "ms_per_step_min_max": [round(min(unmerged_samples) / args.steps * 1e3, 5), round(max(unmerged_samples) / args.steps * 1e3, 5)],
+                             "bytes_per_texel": k1 + k2, "achieved": round(gbps((k1 + k2) * n * n * C, unmerged / args.steps * 1e3), 1),
+                             "frac": round(gbps((k1 + k2) * n * n * C, unmerged / args.steps * 1e3) / HBM_PEAK_GBPS, 4),
+                             "frac_of_copy_ceiling": round(gbps((k1 + k2) * n * n * C, unmerged / args.steps * 1e3) / COPY_CEILING_GBPS, 4),
+                             "kernels": {("k_pass1" + SUFFIX[family] if not (n == 2048 and family == "compact") else "k_pass1c_split"):
+                                             {"avg_ms_events": round(p1_ms, 5), "frac": round(gbps(k1 * n * n * (C / pairs_per_tick), p1_ms) / HBM_PEAK_GBPS, 4)},
+                                         "k_pass2" + SUFFIX[family]:
+                                             {"avg_ms_events": round(p2_ms, 5), "frac": round(gbps(k2 * n * n * (C / pairs_per_tick), p2_ms) / HBM_PEAK_GBPS, 4)}}}}
+               if unmerged is not None else {}),
             "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
                      "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},
@@ -330,8 +399,16 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     if gat is not None:
         out["final_gather_ms"] = round(gather_ms, 3)
         out["gather_bytes"] = {"sent_per_rank": gat.bytes_sent, "received_rank0": gat.bytes_received}
+        out["gather"] = {"mode": args.gather, "every_ticks": gather_every, "overlap": not args.no_overlap, **(cadence or {}),
+                         # what the links deliver: bytes into the consumer per gather / the time between gathers in the timed region
+                         "gathers_per_s": round(args.steps / max(1, gather_every) / elapsed, 2) if gather_every else None,
+                         "root_inbound_gbps": round(gat.bytes_received * (world - 1) / world * (args.steps / max(1, gather_every)) / elapsed / 1e9, 2)
+                                              if gather_every else None}
     if no_gather is not None:
         out["no_gather"] = {"ms_per_step": round(no_gather / args.steps * 1e3, 5), "value": round(maps / no_gather, 2)}
+    if every_tick is not None:
+        out["gather_every_tick"] = {"ms_per_step": round(every_tick / args.steps * 1e3, 5), "value": round(maps / every_tick, 2),
+                                    "root_inbound_gbps": round(gat.bytes_received * (world - 1) / world * args.steps / every_tick / 1e9, 2)}
     return out
 
 
@@ -357,6 +434,8 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
+    if args.cascades is None:
+        args.cascades = 4 if world == 1 else 1  # the headline config (C3) on one GPU; BASELINE config C4's shape (one cascade per GPU) on a node
     configs = SWEEP if args.sweep else [(args.map_size, args.cascades)]
     for n, C in configs:
         out = measure(args, torch, dist, world, rank, local_rank, n, C)

@@ -5,4 +5,5 @@ include/ocean_waves.h).  This package is the thin host-side mirror of the refere
 `WaveGenerator` / `WaveCascadeParameters` interface on top of that ABI.
 """
 from .wave_generator import WaveCascadeParameters, WaveGenerator  # noqa: F401
+from .group import WaveGeneratorGroup  # noqa: F401
 from .presets import cascade_preset, DEPTH, UPDATE_DELTA  # noqa: F401

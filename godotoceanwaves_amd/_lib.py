@@ -7,6 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCEAN_WAVES_LIB") or os.path.join(_HERE, "libocean_waves.so")
 
 OW_MAX_CASCADES = 8
+OW_MAX_DEVICES = 8
+OW_GROUP_FLAG_FORCE_PEER_PATH = 0x10000
 OW_FLAG_DEBUG_F32 = 1
 OW_FLAG_KERNELS_STANDARD = 2
 OW_FLAG_KERNELS_LAYER_PARALLEL = 4
@@ -35,6 +37,12 @@ class ow_config(C.Structure):
     _fields_ = [("map_size", C.c_int32), ("num_cascades", C.c_int32), ("device_id", C.c_int32), ("depth", C.c_float),
                 ("stream", C.c_void_p), ("displacement_map", C.c_void_p), ("normal_map", C.c_void_p),
                 ("flags", C.c_uint32)]
+
+
+class ow_group_config(C.Structure):
+    _fields_ = [("map_size", C.c_int32), ("num_devices", C.c_int32), ("device_ids", C.c_int32 * OW_MAX_DEVICES),
+                ("cascades_per_device", C.c_int32), ("root", C.c_int32), ("depth", C.c_float), ("flags", C.c_uint32),
+                ("displacement_map", C.c_void_p), ("normal_map", C.c_void_p)]
 
 
 # every symbol include/ocean_waves.h declares: (restype, argtypes)
@@ -70,6 +78,22 @@ SIGNATURES = {
     "ow_timing_read": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_int32), C.c_int32]),
     "ow_timing_read_launches": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_int32), C.c_int32]),
     "ow_probe_kernel_times": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_float), _P(C.c_float), _P(C.c_int32)]),
+    "ow_group_create": (C.c_int, [_P(ow_group_config), _P(C.c_void_p)]),
+    "ow_group_destroy": (None, [C.c_void_p]),
+    "ow_group_num_cascades": (C.c_int32, [C.c_void_p]),
+    "ow_group_context": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "ow_group_update": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
+    "ow_group_process": (C.c_int, [C.c_void_p]),
+    "ow_group_update_all": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
+    "ow_group_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),
+    "ow_group_cascades_remaining": (C.c_int32, [C.c_void_p]),
+    "ow_group_sync": (C.c_int, [C.c_void_p]),
+    "ow_group_gather_begin": (C.c_int, [C.c_void_p]),
+    "ow_group_gather_wait": (C.c_int, [C.c_void_p]),
+    "ow_group_gather_stats": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_size_t)]),
+    "ow_group_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
+    "ow_group_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ow_group_sample_surface": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ow_last_error": (C.c_char_p, []),
     "ow_abi_version": (C.c_int32, []),
 }

@@ -18,6 +18,7 @@ UNITS = {
     "ow_spectrum.hip": ["-ffp-contract=off"],
     "ow_runtime.hip": [],
     "ow_consumer.hip": ["-ffp-contract=off"],
+    "ow_group.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -523,6 +523,7 @@ struct CascadeFrame {
 };
 // bits of the device status word (DeviceBuffers::status): set by a kernel, turned into OW_ERR_HIP by the host at the next sync
 constexpr uint32_t kStatusRowSyncTimeout = 1u;  // a wave-pair rendezvous (RowSync, N = 2048) gave up waiting for its partner
+constexpr unsigned long long kRowSyncTimeoutTicks = 2000000ull;  // of wall_clock64() (100 MHz constant clock): 20 ms
 // layer-parallel pass 2: a block = plan_lp_rows(N) rows x 4 lane groups (one per transform) x N/16 lanes (512 threads)
 constexpr int plan_lp_rows(int N) { return 128 / plan_T(N) > 0 ? 128 / plan_T(N) : 1; }
 constexpr int plan_lp_threads(int N) { return plan_lp_rows(N) * kLayers * plan_T(N); }

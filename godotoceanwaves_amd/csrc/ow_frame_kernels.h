@@ -77,18 +77,33 @@ struct RowSync {
             ++epoch;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // s_waitcnt lgkmcnt(0): my LDS reads/writes are done
             if (!mute) *mine = epoch;
-            // bounded: a partner that never arrives (a bug) must not hang the device; 2^18 polls of >= 64 clocks is > 5 ms, three
-            // orders of magnitude beyond the kernel's whole duration.  Giving up is REPORTED: the status word makes the next
-            // ow_sync fail, the results of this batch are garbage.
+            // bounded: a partner that never arrives (a bug) must not hang the device.  The bound is WALL TIME, not a poll count: ~20 ms
+            // of the 100 MHz constant clock (checked every 256 polls), four orders of magnitude beyond the kernel's whole duration, so
+            // that a stalled partner (a page migration under caller-owned buffers, a debugger) is not mistaken for a missing one.
+            // Giving up is REPORTED: the status word makes the next synchronising call fail, the results of this batch are garbage
+            // (and its foam state with them: ocean_waves.h, ow_sync).  The report is a plain system-scope store of the one bit that
+            // exists, followed by a system fence -- no read-modify-write, so it does not depend on PCIe atomics towards host memory.
             if (!dead) {
                 int spin = 0;
-                while (__builtin_amdgcn_readfirstlane(*partner) < epoch && spin < (1 << 18)) {
+                unsigned long long t0 = 0;
+                bool gave_up = false;
+                while (__builtin_amdgcn_readfirstlane(*partner) < epoch) {
                     __builtin_amdgcn_s_sleep(1);
-                    ++spin;
+                    if ((++spin & 255) == 0) {
+                        const unsigned long long now = wall_clock64();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > kRowSyncTimeoutTicks) {
+                            gave_up = true;
+                            break;
+                        }
+                    }
                 }
-                if (spin == (1 << 18)) {
+                if (gave_up) {
                     dead = true;
-                    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, kStatusRowSyncTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((threadIdx.x & 63) == 0) {
+                        __hip_atomic_store(status, kStatusRowSyncTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __threadfence_system();
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");

@@ -19,13 +19,15 @@
 #include <vector>
 
 #include "../../include/ocean_waves.h"
+#include "ow_internal.h"
 #include "ow_kernels.h"
 #include "ow_tables.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
+namespace ow {
 ow_status fail(ow_status st, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -35,15 +37,12 @@ ow_status fail(ow_status st, const char *fmt, ...) {
     g_last_error = buf;
     return st;
 }
+void set_last_error(const char *message) { g_last_error = message ? message : ""; }
+}  // namespace ow
 
-#define OW_HIP(call)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess) return fail(OW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
+namespace {
+using ow::fail;
 constexpr double kHostG = 9.81;  // wave_generator.gd:5
-
 }  // namespace
 
 struct ow_context {
@@ -65,10 +64,16 @@ struct ow_context {
     // device-side spin that gave up), every synchronising entry point turns a non-zero word into OW_ERR_HIP
     uint32_t *status_host = nullptr;
     uint32_t inject_fault = 0;  // ow_debug_inject_fault: applied to the next batch only
+    // The status word is consumed by the first synchronising call that sees it; the failure itself is sticky: until the next batch
+    // is enqueued every call that hands out map bytes (ow_get_maps, ow_get_maps_f32, ow_sample_surface) keeps failing, and so does
+    // the ow_readback_wait of every layer whose copy was in flight when the word was consumed (readback_faulted).
+    bool maps_faulted = false;
+    uint32_t readback_faulted = 0;
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
     int group_p1_form = -1, group_p2_form = -1;
-    int group_max_count = 0, group_depth = 0;
+    int group_max_count = 0, group_depth = 0;  // (group_depth: the depth of a run of group_max_count cascades; a run's own depth follows its count)
+    int scratch_slots = 0;  // launch slots the scratch intermediate (T, pcol, rrow) holds now: one batch at create, grown by the first ow_run that merges launches
     // ow_run's tick pairs on the compact family (k_tick_pair_c): the largest batch they launch (0 = never); scratch two batches deep
     int pair_slots = 0;
     int last_group_depth = 0;  // ticks per launch of the most recent ow_run that went out in groups / pairs
@@ -145,6 +150,13 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
     if (B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) return 0;
     return B;
 }
+// ticks per launch of a run of `count` cascades in tick groups: four; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick)
+// -- deeper groups pay only there; never more than fits kGroupScratchBytes twice over (the intermediates are double-buffered)
+int tick_group_depth_for(const ow_context *c, int count) {
+    const size_t per_tick = (size_t)count * c->n * c->n * ow::kLayers * sizeof(ow::cplx);
+    const size_t cap = per_tick <= ((size_t)8 << 20) ? ow::kMaxTickGroup : 4;
+    return (int)std::min<size_t>(cap, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
+}
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
@@ -156,19 +168,46 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     for (int count = 1; count <= c->cascades; ++count)
         if (ow::kernel_family(c->n, count, c->kernel_mode) == 4) best = count;
     if (best == 0) return;
-    const size_t per_tick = (size_t)best * c->n * c->n * ow::kLayers * sizeof(ow::cplx);
     c->group_max_count = best;
-    // four ticks per group; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick) -- deeper groups pay only there
-    const size_t cap = per_tick <= ((size_t)8 << 20) ? ow::kMaxTickGroup : 4;
-    c->group_depth = (int)std::min<size_t>(cap, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
+    c->group_depth = tick_group_depth_for(c, best);
     // measurement knob (scripts/group_p1_body.py): force one pass-1 item form in the tick groups; -1 = the runtime's own choice
     c->group_p1_form = -1;
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
     c->group_p2_form = -1;
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P2")) c->group_p2_form = strcmp(e, "pipe") == 0 ? 1 : strcmp(e, "plain") == 0 ? 0 : -1;
 }
-int scratch_slots(const ow_context *c) {
-    return std::max({std::min(c->layers, max_batch(c)), 2 * c->group_depth * c->group_max_count, 2 * c->pair_slots});
+// The scratch intermediate of ONE batch is all that ow_update / ow_process / ow_update_all ever need, and all that ow_create
+// allocates; the merged launches of ow_run keep 2 * depth ticks (groups) or two batches (pairs) in flight and grow it on first use.
+int base_scratch_slots(const ow_context *c) { return std::min(c->layers, max_batch(c)); }
+ow_status ensure_scratch(ow_context *c, int slots) {
+    if (slots <= c->scratch_slots) return OW_OK;
+    const size_t pl = (size_t)c->n * c->n;
+    ow::cplx *T = nullptr, *pcol = nullptr, *rrow = nullptr;
+    if (hipMalloc((void **)&T, (size_t)slots * pl * ow::kLayers * sizeof(ow::cplx)) != hipSuccess ||
+        hipMalloc((void **)&pcol, (size_t)slots * c->n * sizeof(ow::cplx)) != hipSuccess ||
+        hipMalloc((void **)&rrow, (size_t)slots * c->n * 4 * sizeof(ow::cplx)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(T);
+        (void)hipFree(pcol);
+        (void)hipFree(rrow);
+        return fail(OW_ERR_NOMEM, "hipMalloc failed for %d launch slots of scratch intermediate (%zu bytes)", slots, (size_t)slots * pl * ow::kLayers * sizeof(ow::cplx));
+    }
+    // the old scratch may still be in use by launches already enqueued (it is dead once they have finished: scratch of one batch)
+    if (c->buf.T && hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(T);
+        (void)hipFree(pcol);
+        (void)hipFree(rrow);
+        return fail(OW_ERR_HIP, "hipStreamSynchronize failed while growing the scratch intermediate");
+    }
+    (void)hipFree(c->buf.T);
+    (void)hipFree(c->buf.pcol);
+    (void)hipFree(c->buf.rrow);
+    c->buf.T = T;
+    c->buf.pcol = pcol;
+    c->buf.rrow = rrow;
+    c->scratch_slots = slots;
+    for (int &sl : c->slot_of) sl = -1;  // (the reference-layout view of the last batch's intermediate went with the old buffer)
+    return OW_OK;
 }
 
 constexpr size_t kMaxTimedBatches = 4096;
@@ -210,17 +249,44 @@ ow_status next_events(ow_context *c, hipEvent_t **out, bool single = false) {
     return OW_OK;
 }
 
-// hipStreamSynchronize + the device status word
-ow_status sync_stream(ow_context *c) {
+// hipStreamSynchronize + the device status word.  hands_out_maps: the caller is about to give map bytes to its caller (everything
+// but a bare ow_sync), which stays refused after a consumed failure until the maps have been recomputed.
+ow_status sync_stream(ow_context *c, bool hands_out_maps = true) {
     OW_HIP(hipStreamSynchronize(c->stream));
     if (c->status_host && *c->status_host != 0u) {
         const uint32_t bits = *c->status_host;
-        *c->status_host = 0u;  // reported once; later batches start clean
+        *c->status_host = 0u;  // the word is consumed; later batches start clean ...
+        c->maps_faulted = true;  // ... but what the faulted batches left behind stays marked until the maps are recomputed
+        for (int i = 0; i < OW_MAX_CASCADES; ++i)
+            if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
         return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
                                 "the last synchronisation are invalid", bits, (bits & ow::kStatusRowSyncTimeout) ? ": wave-pair rendezvous timed out" : "");
     }
+    if (c->maps_faulted && hands_out_maps)
+        return fail(OW_ERR_HIP, "the maps are those of a batch that reported a device-side failure (already returned by an earlier call); "
+                                "they stay invalid until the next batch has been enqueued");
     return OW_OK;
 }
+
+}  // namespace
+namespace ow {
+// The device status word WITHOUT synchronising: for a caller that has waited by other means (the group's gather waits on its own
+// copy events) and is about to hand out map bytes.  Same consumption / stickiness as sync_stream.
+ow_status poll_status(ow_context *c) {
+    if (c->status_host && *c->status_host != 0u) {
+        const uint32_t bits = *c->status_host;
+        *c->status_host = 0u;
+        c->maps_faulted = true;
+        for (int i = 0; i < OW_MAX_CASCADES; ++i)
+            if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
+        return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x): the maps of the batches enqueued since the last "
+                                "synchronisation are invalid", bits);
+    }
+    if (c->maps_faulted) return fail(OW_ERR_HIP, "the maps are those of a batch that reported a device-side failure; they stay invalid until the next batch has been enqueued");
+    return OW_OK;
+}
+}  // namespace ow
+namespace {
 
 bool finite_record(const ow_cascade_params &p) {
     const float f[] = {p.tile_length[0], p.tile_length[1], p.wind_speed, p.wind_direction, p.fetch_length, p.swell, p.spread, p.detail,
@@ -230,18 +296,37 @@ bool finite_record(const ow_cascade_params &p) {
     return std::isfinite(p.time) && std::isfinite(p.foam_grow_rate) && std::isfinite(p.foam_decay_rate);
 }
 
+// A record the kernels can take: every field finite, tile_length positive.  Checked where a record ENTERS the context (ow_update,
+// ow_set_cascade_params) -- before anything of the caller's is changed and before anything is armed -- so that a refused record
+// leaves no trace; enqueue() repeats the check as a guard only.
+ow_status validate_record(const ow_cascade_params &p, int index) {
+    if (!finite_record(p)) return fail(OW_ERR_INVALID, "cascade %d: non-finite parameter", index);
+    if (!(p.tile_length[0] > 0.0f) || !(p.tile_length[1] > 0.0f)) return fail(OW_ERR_INVALID, "cascade %d: tile_length must be positive", index);
+    return OW_OK;
+}
+}  // namespace
+namespace ow {
+// what ow_update checks before it changes anything (a group checks ALL shards' records with it before any shard starts)
+ow_status validate_records(const ow_cascade_params *params, int count, double delta) {
+    if (!std::isfinite(delta)) return fail(OW_ERR_INVALID, "delta is not finite");
+    for (int i = 0; i < count; ++i) {
+        if (ow_status st = validate_record(params[i], i); st != OW_OK) return st;
+        if (!std::isfinite(params[i].time + delta)) return fail(OW_ERR_INVALID, "cascade %d: time + delta is not finite", i);
+    }
+    return OW_OK;
+}
+}  // namespace ow
+namespace {
+
 // _update() for a batch of cascade indices (wave_generator.gd:65-85)
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     // everything is validated before anything is launched: a bad record must not leave the batch half enqueued
-    for (int i = 0; i < count; ++i) {
-        const ow_cascade_params &p = params[idx[i]];
-        if (!finite_record(p)) return fail(OW_ERR_INVALID, "cascade %d: non-finite parameter", idx[i]);
-        if (!(p.tile_length[0] > 0.0f) || !(p.tile_length[1] > 0.0f))
-            return fail(OW_ERR_INVALID, "cascade %d: tile_length must be positive", idx[i]);
-    }
+    for (int i = 0; i < count; ++i)
+        if (ow_status st = validate_record(params[idx[i]], idx[i]); st != OW_OK) return st;
+    c->maps_faulted = false;  // a new batch recomputes the maps (the foam state a faulted batch left behind is the caller's to restore)
     for (int i = 0; i < count; ++i) {
         ow_cascade_params &p = params[idx[i]];
         if (p.should_generate_spectrum) {  // :68-72
@@ -395,7 +480,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
     plan_tick_groups(c, cfg->flags);
-    OW_ALLOC(c->buf.T, (size_t)scratch_slots(c) * pl * ow::kLayers * sizeof(ow::cplx));
+    if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -410,11 +495,6 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     }
     OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
     if (cfg->flags & OW_FLAG_DEBUG_F32) { OW_ALLOC(c->buf.f32, L * pl * 8 * sizeof(float)); }
-    {   // side buffers of the compact intermediate, one batch worth like T
-        const size_t slots = (size_t)scratch_slots(c);
-        OW_ALLOC(c->buf.pcol, slots * c->n * sizeof(ow::cplx));
-        OW_ALLOC(c->buf.rrow, slots * c->n * 4 * sizeof(ow::cplx));
-    }
     if (hipHostMalloc((void **)&c->status_host, 64, hipHostMallocMapped) != hipSuccess)
         return bail(fail(OW_ERR_NOMEM, "hipHostMalloc failed for the device status word"));
     *c->status_host = 0u;
@@ -484,13 +564,19 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
     if (count < 1 || count > c->cascades)  // assert(parameters.size() != 0), :91
         return fail(OW_ERR_INVALID, "count %d outside [1,%d]", count, c->cascades);
     if (!std::isfinite(delta)) return fail(OW_ERR_INVALID, "delta is not finite");
+    // the new records are checked BEFORE anything changes: a refused call has advanced no time, consumed no dirty flag, armed nothing
+    if (ow_status st = ow::validate_records(params, count, delta); st != OW_OK) return st;
     OW_HIP(hipSetDevice(c->device));
     if (c->pass_num_cascades_remaining != 0) {  // :94-98: leftovers of the previous arm, with the previous records
         int idx[OW_MAX_CASCADES];
-        for (int i = 0; i < c->pass_num_cascades_remaining; ++i) idx[i] = i;
-        ow_status st = enqueue(c, c->pass_parameters, idx, c->pass_num_cascades_remaining);
-        if (st != OW_OK) return st;
+        const int left = c->pass_num_cascades_remaining;
+        for (int i = 0; i < left; ++i) idx[i] = i;
+        // Whatever happens to them, the leftovers do not survive this call: were a failed flush to stay armed, every later
+        // ow_update would run into it again.  (Armed records were validated on the way in, so only a HIP failure can end up here;
+        // nothing of `params` has been touched yet, so the call can simply be repeated.)
         c->pass_num_cascades_remaining = 0;
+        ow_status st = enqueue(c, c->pass_parameters, idx, left);
+        if (st != OW_OK) return st;
     }
     for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
         ow_cascade_params &p = params[i];
@@ -509,6 +595,7 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
 ow_status ow_set_cascade_params(ow_context *c, int32_t index, const ow_cascade_params *p) {
     if (!c || !p) return fail(OW_ERR_INVALID, "null argument");
     if (index < 0 || index >= c->pass_count) return fail(OW_ERR_INVALID, "index %d outside the %d records of the last ow_update", index, c->pass_count);
+    if (ow_status st = validate_record(*p, index); st != OW_OK) return st;  // a refused record leaves the armed copy as it was
     c->pass_parameters[index] = *p;
     return OW_OK;
 }
@@ -563,7 +650,7 @@ int tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int
     for (int i = 0; i < count; ++i)
         if (params[i].should_generate_spectrum || !finite_record(params[i]) || !(params[i].tile_length[0] > 0.0f) || !(params[i].tile_length[1] > 0.0f))
             return 0;  // (the ordinary path regenerates / reports)
-    return groups ? c->group_depth : -1;
+    return groups ? tick_group_depth_for(c, count) : -1;
 }
 
 // one more ow_update_all() worth of arithmetic on the records (wave_generator.gd:101-106); time_out[i] = FP32 time of launch
@@ -718,6 +805,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     const int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
     if (depth != 0) {
         OW_HIP(hipSetDevice(c->device));
+        if (ow_status st = ensure_scratch(c, depth > 0 ? 2 * depth * count : 2 * c->pair_slots); st != OW_OK) return st;
         ow_status st = depth > 0 ? run_tick_groups(c, delta, params, count, frames - f, depth) : run_tick_pairs(c, delta, params, count, frames - f);
         if (st != OW_OK) return st;
         f = frames;
@@ -741,7 +829,7 @@ int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_casc
 ow_status ow_sync(ow_context *c) {
     if (!c) return fail(OW_ERR_INVALID, "null context");
     OW_HIP(hipSetDevice(c->device));
-    return sync_stream(c);
+    return sync_stream(c, false);
 }
 
 ow_status ow_get_device_ptrs(ow_context *c, void **disp, void **norm, size_t *stride) {
@@ -801,6 +889,7 @@ ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
         ow::u16x4 *hd = c->snap_host + (size_t)i * pl, *hn = c->snap_host + (L + i) * pl;
         // the snapshot slot may still be feeding an earlier PCIe copy
         if (c->copy_pending[i]) OW_HIP(hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
+        c->readback_faulted &= ~(1u << i);  // a new snapshot of this layer
         OW_HIP(hipMemcpyAsync(sd, c->buf.disp + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
         OW_HIP(hipMemcpyAsync(sn, c->buf.norm + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
         OW_HIP(hipEventRecord(c->snap_ready[i], c->stream));
@@ -820,7 +909,14 @@ ow_status ow_readback_wait(ow_context *c, int32_t cascade, const void **disp, co
     OW_HIP(hipSetDevice(c->device));
     OW_HIP(hipEventSynchronize(c->copy_done[cascade]));
     c->copy_pending[cascade] = false;
-    if (*c->status_host != 0u) return sync_stream(c);  // a frame kernel reported a failure: the bytes that landed are not maps
+    if (*c->status_host != 0u) {  // a frame kernel reported a failure: the bytes that landed are not maps
+        c->readback_faulted |= 1u << cascade;  // (copy_pending was just cleared: mark this layer by hand, the others are marked by sync_stream)
+        (void)sync_stream(c);
+    }
+    if ((c->readback_faulted >> cascade) & 1u) {  // every layer of the faulted batch fails, not only the first one waited for
+        c->readback_faulted &= ~(1u << cascade);
+        return fail(OW_ERR_HIP, "the readback of cascade %d carries maps of a batch that reported a device-side failure", cascade);
+    }
     const size_t pl = plane(c), L = (size_t)c->layers;
     if (disp) *disp = c->snap_host + (size_t)cascade * pl;
     if (norm) *norm = c->snap_host + (L + cascade) * pl;

@@ -24,7 +24,11 @@ extern "C" {
 #endif
 
 #define OW_MAX_CASCADES 8 /* MAX_CASCADES, assets/shaders/spatial/water.gdshader:8 */
-#define OW_ABI_VERSION 2 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word */
+#define OW_MAX_DEVICES 8  /* the GPUs of one node */
+#define OW_ABI_VERSION 3 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word;
+                            3: ow_group_* (cascades sharded over several devices, gather into the consumer's arrays), records are
+                               validated on the way in (ow_update / ow_set_cascade_params), sticky device-side failures,
+                               ow_export/import_maps (dma-buf hand-off) */
 
 typedef enum ow_status {
     OW_OK = 0,
@@ -127,16 +131,19 @@ void ow_cascade_params_default(ow_cascade_params *p);
  * The reference keeps a reference to the caller's Array and reads the live objects later; a C caller's memory is
  * only borrowed DURING this call: the context keeps a COPY of the `count` records (a managed caller pins its array for
  * the call and no longer).  `should_generate_spectrum` is consumed: the armed copy carries it until the cascade is
- * processed, and it is cleared in `params`, so an unchanged array does not regenerate its spectra every tick.  A record
- * with a non-finite field or a non-positive tile_length is refused with OW_ERR_INVALID when its cascade is enqueued;
- * nothing of that batch is launched. */
+ * processed, and it is cleared in `params`, so an unchanged array does not regenerate its spectra every tick.
+ * Errors leave no trace: all `count` records are checked first (every field finite, tile_length positive, time + delta
+ * finite) and a refused call (OW_ERR_INVALID) has advanced no time, consumed no dirty flag, armed and launched nothing -- the
+ * corrected array simply goes in again.  Leftovers of the previous arm never survive this call: if their flush fails
+ * (only a HIP failure can make it) they are dropped, `params` is still untouched, and the call can be repeated. */
 ow_status ow_update(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
 
 /* "The parameter objects are live" made explicit: replace / read the context's copy of armed record `index`
  * (0 <= index < count of the last ow_update).  A caller that lets the user edit parameters between ow_update and the
  * ow_process that consumes them (the reference reads the edited object, wave_generator.gd:56-72) pushes the edited record
  * with ow_set_cascade_params before that ow_process; ow_get_cascade_params returns the record as the generator left it
- * (should_generate_spectrum cleared once the cascade has been processed, :72). */
+ * (should_generate_spectrum cleared once the cascade has been processed, :72).  A record the kernels cannot take is refused
+ * (OW_ERR_INVALID) and the armed copy stays as it was. */
 ow_status ow_set_cascade_params(ow_context *ctx, int32_t index, const ow_cascade_params *params);
 ow_status ow_get_cascade_params(const ow_context *ctx, int32_t index, ow_cascade_params *out);
 
@@ -158,8 +165,13 @@ int32_t ow_cascades_remaining(const ow_context *ctx);
 /* Blocks until everything enqueued by this context has finished.  Also the point where a device-side failure shows: the
  * frame kernels OR a bit into the context's status word when a bounded wait gives up (the wave-pair rendezvous of the
  * 2048^2 kernels); a non-zero word turns this call -- and every other call that synchronises: ow_get_maps,
- * ow_get_maps_f32, ow_readback_wait, ow_sample_surface -- into OW_ERR_HIP (reported once, then cleared).  The maps of
- * the batches enqueued since the previous synchronisation are then invalid. */
+ * ow_get_maps_f32, ow_readback_wait, ow_sample_surface -- into OW_ERR_HIP.  The maps of the batches enqueued since the previous
+ * synchronisation are then invalid, and so is the foam state they left behind (restore it with ow_set_normal_map).  The word
+ * itself is consumed by the first call that sees it (ow_sync reports it once), but the failure is sticky for everything that
+ * hands out map bytes: ow_get_maps, ow_get_maps_f32, ow_sample_surface and the ow_readback_wait of EVERY layer whose copy
+ * was in flight keep returning OW_ERR_HIP until the next batch has been enqueued (or, for a layer's readback, until its next
+ * ow_readback_begin).  The device-side wait is bounded by wall time (20 ms), and the report is a plain store + system fence
+ * into page-locked host memory: it needs no PCIe atomics. */
 ow_status ow_sync(ow_context *ctx);
 
 /* ---- outputs: descriptors[&'displacement_map'/'normal_map'] (wave_generator.gd:34-35, water.gd:95-96) ---- */
@@ -220,6 +232,70 @@ typedef struct ow_surface_sample {
  * all host pointers) after everything enqueued so far, and writes `count` records.  Synchronises. */
 ow_status ow_sample_surface(ow_context *ctx, const float *world_xz, int32_t count, const float *map_scales,
                             int32_t num_cascades, ow_surface_sample *out);
+
+/* ---- several devices: cascades sharded inside one process ---------------------------------------- */
+
+/* Cascades share nothing (wave_generator.gd:65-85 touches no state of another cascade; README.md:77-80), so a node's GPUs
+ * each take a block of them: shard s owns the global cascades s*cascades_per_device .. +cascades_per_device-1 with all
+ * their state (h0, foam, time) in its own ow_context on device_ids[s].  There is no data-path exchange.  The ONE
+ * exchange is the gather of finished layers into the consumer's arrays on the root device -- the two RGBA16F array
+ * textures water.gd:95-100 binds, layer g = global cascade g -- and only the owned layers travel:
+ *     ow_group_gather_begin : per shard, in the shard's stream order: snapshot of the owned layers (device-to-device), then
+ *                             on a side stream hipMemcpyPeerAsync over xGMI into the root's layer slots; returns at once,
+ *                             later ticks overlap the transfer and may overwrite the live maps;
+ *     ow_group_gather_wait  : blocks until every shard's layers have landed.
+ * A shard on the root device itself copies straight into its slots (no second hop).  Each shard is driven by its own
+ * worker thread (launches on N devices are enqueued side by side, not one device after the other); the group, like a
+ * context, takes one caller thread. */
+typedef struct ow_group_config {
+    int32_t map_size;                   /* as ow_config */
+    int32_t num_devices;                /* shards, 1..OW_MAX_DEVICES */
+    int32_t device_ids[OW_MAX_DEVICES]; /* HIP ordinal of each shard; an ordinal may repeat (several shards on one device) */
+    int32_t cascades_per_device;        /* >= 1; num_devices * cascades_per_device is the group's cascade count (beyond the reference's
+                                           MAX_CASCADES = 8 the arrays are tiles of independent oceans, not one shader's cascades) */
+    int32_t root;                       /* index into device_ids: the consumer's device, where the gathered arrays live */
+    float depth;                        /* as ow_config */
+    uint32_t flags;                     /* OW_FLAG_* for every shard, | OW_GROUP_FLAG_* */
+    void *displacement_map;             /* optional caller-owned buffers ON THE ROOT DEVICE for the gathered arrays, */
+    void *normal_map;                   /* max(2, cascades) * N * N * 8 bytes each; NULL = the group allocates */
+} ow_group_config;
+/* Test hook: treat every shard as remote (snapshot + side stream + hipMemcpyPeerAsync) even where it shares the root's device, so
+ * that the whole peer path runs on a single-GPU box. */
+#define OW_GROUP_FLAG_FORCE_PEER_PATH 0x10000u
+
+typedef struct ow_group ow_group;
+
+ow_status ow_group_create(const ow_group_config *config, ow_group **out);
+void ow_group_destroy(ow_group *group);
+int32_t ow_group_num_cascades(const ow_group *group);
+/* the context of shard `shard` (borrowed: for per-shard queries such as ow_get_maps / ow_last_kernel_family; do not destroy) */
+ow_context *ow_group_context(ow_group *group, int32_t shard);
+
+/* ow_update / ow_process / ow_update_all / ow_run over the whole group: `params` holds the records of ALL cascades in global
+ * order (count == ow_group_num_cascades), shard s works on its slice.  ow_group_process keeps the reference's order -- one armed
+ * cascade per call, highest global index first (wave_generator.gd:56-63).  The first failing shard's status is returned; its
+ * message is ow_last_error(). */
+ow_status ow_group_update(ow_group *group, double delta, ow_cascade_params *params, int32_t count);
+ow_status ow_group_process(ow_group *group);
+ow_status ow_group_update_all(ow_group *group, double delta, ow_cascade_params *params, int32_t count);
+ow_status ow_group_run(ow_group *group, double delta, ow_cascade_params *params, int32_t count, int32_t frames);
+int32_t ow_group_cascades_remaining(const ow_group *group);
+/* ow_sync of every shard (and of an outstanding gather) */
+ow_status ow_group_sync(ow_group *group);
+
+ow_status ow_group_gather_begin(ow_group *group);
+ow_status ow_group_gather_wait(ow_group *group);
+/* Duration (ms, begin of the first to end of the last copy, per shard, maximum over shards) and volume of the most recent completed
+ * gather's inter-device copies; bytes_per_shard = cascades_per_device * N * N * 16. */
+ow_status ow_group_gather_stats(ow_group *group, float *max_copy_ms, size_t *bytes_per_shard);
+
+/* The gathered arrays on the root device (layout as ow_get_device_ptrs; layer g = global cascade g), as of the last gather. */
+ow_status ow_group_get_device_ptrs(ow_group *group, void **displacement_map, void **normal_map, size_t *layer_stride_bytes);
+/* Host copy of one gathered layer (as ow_get_maps); needs a completed gather (OW_ERR_STATE before the first one). */
+ow_status ow_group_get_maps(ow_group *group, int32_t cascade, void *displacement_rgba16f, void *normal_rgba16f);
+/* ow_sample_surface over the gathered arrays on the root device: what the consumer's shaders see (num_cascades <= 8 layers from 0). */
+ow_status ow_group_sample_surface(ow_group *group, const float *world_xz, int32_t count, const float *map_scales, int32_t num_cascades,
+                                  ow_surface_sample *out);
 
 /* ---- parity / debug ------------------------------------------------------------------------------ */
 

@@ -27,6 +27,11 @@ CASES = [  # (map_size, cascade preset id, frames, row stride of the stored maps
     # three frames: what ow_run(3) leaves behind after one ordinary tick and two merged launches (tick groups / tick pairs)
     (512, 3, 3, 16),
     (1024, 2, 3, 64),
+    # the other two cascades of the headline batch (1024^2 x 4 = presets 0..3): with ref_n1024_c0_f3 / c1 / c2 / c3 every cascade of the
+    # bench configuration is held to bytes of the reference's own shaders after ow_run(3)
+    (1024, 1, 3, 64),
+    (1024, 3, 3, 64),
+    (1024, 0, 3, 64),
 ]
 
 

@@ -49,6 +49,13 @@ def test_struct_layout_matches_ctypes(lib):
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     P, Cfg = _lib.ow_cascade_params, _lib.ow_config
     assert got == [C.sizeof(P), P.spectrum_seed.offset, P.time.offset, C.sizeof(Cfg), Cfg.stream.offset, Cfg.flags.offset]
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "ocean_waves.h"\nint main(void){printf("%zu %zu %zu %zu %zu %d\\n",'
+           'sizeof(ow_group_config), offsetof(ow_group_config, device_ids), offsetof(ow_group_config, root),'
+           'offsetof(ow_group_config, flags), offsetof(ow_group_config, normal_map), OW_MAX_DEVICES);return 0;}\n')
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
+    got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    G = _lib.ow_group_config
+    assert got == [C.sizeof(G), G.device_ids.offset, G.root.offset, G.flags.offset, G.normal_map.offset, _lib.OW_MAX_DEVICES]
 
 
 def test_defaults_match_reference(lib):

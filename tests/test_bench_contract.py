@@ -43,4 +43,8 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["kernel"].startswith(kernel)
     assert 0.0 < rf["frac"] < 0.85 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3      # a bandwidth, below the copy ceiling
     assert rf["frac_of_copy_ceiling"] < 1.0
+    # the interactive path's figure (one launch per pass: what ow_update_all / ow_process callers get) and the residency note
+    um, res = rf["unmerged"], rf["residency"]
+    assert um["ms_per_step"] >= 0.9 * d["ms_per_step"] and 0.0 < um["frac"] < 0.85 and um["value"] > 0 and len(um["kernels"]) == 2
+    assert res["reused_bytes"] == res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"] and res["infinity_cache_bytes"] == 256 << 20
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0

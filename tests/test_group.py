@@ -1,0 +1,201 @@
+"""Cascades sharded over several devices INSIDE one process: the C-ABI's ow_group_* (include/ocean_waves.h "several devices",
+SURVEY.md 8e).  The GPU box has ONE MI355X, so the group is two (or four) shards on device 0 -- with
+OW_GROUP_FLAG_FORCE_PEER_PATH every shard goes through the whole remote path: snapshot in stream order, side stream,
+hipMemcpyPeerAsync (to self) into the consumer's layer slots.  Cascades are independent (wave_generator.gd:65-85), so what a
+shard computes is bit for bit what a lone context with the same cascades computes, and the gathered arrays have to hold exactly
+those bytes AS OF the gather_begin call, while later ticks overwrite the live maps."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, WaveGeneratorGroup, _lib
+from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def lone(n, ids, ticks, run=True):
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.init_gpu(max(2, len(ids)))
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    if run:
+        gen.run(UPDATE_DELTA, params, ticks)
+    else:
+        for _ in range(ticks):
+            gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    return gen, params
+
+
+def bits(a):
+    return np.asarray(a).view(np.uint16)
+
+
+@pytest.mark.parametrize("force_peer", [True, False], ids=["peer_path", "same_device_path"])
+@pytest.mark.parametrize("n,shards,per", [(256, 2, 2), (512, 4, 1), (1024, 2, 1)])
+def test_gathered_arrays_hold_the_snapshot_of_every_shard(n, shards, per, force_peer):
+    ids = list(range(shards * per))
+    grp = WaveGeneratorGroup()
+    grp.map_size = n
+    grp.force_peer_path = force_peer
+    grp.init_gpu([0] * shards, per, root=shards - 1)
+    assert grp.num_cascades == len(ids)
+    with pytest.raises(_lib.OceanWavesError) as e:   # nothing gathered yet
+        grp.get_maps(0)
+    assert e.value.status == _lib.OW_ERR_STATE
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    grp.run(UPDATE_DELTA, params, 5)
+    grp.gather_begin()                 # snapshot of tick 5 ...
+    grp.run(UPDATE_DELTA, params, 4)   # ... while four more ticks overwrite the live maps
+    grp.gather_wait()
+    ms, nbytes = grp.gather_stats()
+    assert nbytes == per * n * n * 16 and ms > 0.0
+    for s in range(shards):
+        twin, _ = lone(n, ids[s * per:(s + 1) * per], 5)
+        for l in range(per):
+            want_d, want_n = twin.get_maps(l)
+            got_d, got_n = grp.get_maps(s * per + l)
+            assert np.array_equal(bits(got_d), bits(want_d)) and np.array_equal(bits(got_n), bits(want_n)), (s, l)
+            live_d, _ = grp.shard(s).get_maps(l)   # the live maps have moved on
+            assert not np.array_equal(bits(live_d), bits(want_d))
+        twin.free()
+    # a second gather replaces the first (the snapshot buffer is reused only after its copy has left)
+    grp.gather_begin()
+    grp.gather_wait()
+    grp.sync()
+    for s in range(shards):
+        for l in range(per):
+            live = grp.shard(s).get_maps(l)
+            got = grp.get_maps(s * per + l)
+            assert np.array_equal(bits(got[0]), bits(live[0])) and np.array_equal(bits(got[1]), bits(live[1]))
+    assert params[0].time == pytest.approx(120.0 + 9 * UPDATE_DELTA)
+    grp.free()
+
+
+def test_group_keeps_the_reference_schedule_one_cascade_per_frame_highest_index_first():
+    """ow_group_update arms every shard; ow_group_process drains one cascade per call, highest GLOBAL index first
+    (wave_generator.gd:56-63); the result equals update_all on the same records."""
+    n, shards, per = 256, 2, 2
+    ids = list(range(shards * per))
+    a, b = WaveGeneratorGroup(), WaveGeneratorGroup()
+    for g in (a, b):
+        g.map_size = n
+        g.init_gpu([0] * shards, per)
+    pa = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    pb = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    for tick in range(3):
+        a.update(UPDATE_DELTA, pa)
+        assert a.pass_num_cascades_remaining == 4
+        order = []
+        while a.pass_num_cascades_remaining:
+            rem = [int(a._lib.ow_cascades_remaining(a._lib.ow_group_context(a.group, s))) for s in range(shards)]
+            order.append(rem)
+            a._process()
+        assert order == [[2, 2], [2, 1], [2, 0], [1, 0]]
+        a._process()  # nothing armed: a no-op
+        b.update_all(UPDATE_DELTA, pb)
+    # leftovers are flushed by the next update (wave_generator.gd:94-98): arm, drain one, update again
+    a.update(UPDATE_DELTA, pa)
+    a._process()
+    a.update(UPDATE_DELTA, pa)
+    while a.pass_num_cascades_remaining:
+        a._process()
+    b.update_all(UPDATE_DELTA, pb)
+    b.update_all(UPDATE_DELTA, pb)
+    for g in (a, b):
+        g.gather_begin()
+        g.gather_wait()
+    for c in ids:
+        da, na = a.get_maps(c)
+        db, nb = b.get_maps(c)
+        assert np.array_equal(bits(da), bits(db)) and np.array_equal(bits(na), bits(nb)), c
+    assert [p.time for p in pa] == [p.time for p in pb]
+    a.free()
+    b.free()
+
+
+def test_c4_shape_against_the_reference_shaders_bytes():
+    """BASELINE config C4 in miniature -- 1024^2, ONE cascade per shard, gather to the consumer: after ow_group_run(3) the gathered
+    layer of every global cascade that has a committed fixture is held to the bytes the reference's own shaders produced
+    (tests/golden/ref_n1024_c*_f3.npz)."""
+    fixtures = {int(np.load(p)["cascade"]): p for p in sorted(glob.glob(os.path.join(GOLDEN, "ref_n1024_c*_f3.npz")))}
+    assert fixtures
+    shards = max(fixtures) + 1
+    grp = WaveGeneratorGroup()
+    grp.map_size = 1024
+    grp.force_peer_path = True
+    grp.init_gpu([0] * shards, 1)
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in range(shards)]
+    grp.run(UPDATE_DELTA, params, 3)
+    grp.gather_begin()
+    grp.gather_wait()
+    assert grp.shard(0).last_kernel_family() == "tick_groups_compact"
+    for ci, path in fixtures.items():
+        z = np.load(path)
+        stride = int(z["row_stride"])
+        disp, norm = grp.get_maps(ci)
+        assert H.fp16_close(disp[::stride], z["displacement"]) <= 1.0
+        assert H.fp16_close(norm[::stride][..., :3], z["normal"][..., :3]) <= 1.0
+        foam, foam_ref = norm[::stride][..., 3].astype(np.float64), z["normal"][..., 3].view(np.float16).astype(np.float64)
+        assert np.abs(foam - foam_ref).max() <= H.TOL_FOAM_ABS
+    grp.free()
+
+
+def test_consumer_sampling_over_the_gathered_arrays_is_the_oracles():
+    """what the consumer's shaders see on the root device (water.gdshader:31-37,72-82 over all cascades) = the oracle's restatement
+    evaluated on the gathered bytes, bit for bit"""
+    n, shards, per = 256, 3, 1
+    grp = WaveGeneratorGroup()
+    grp.map_size = n
+    grp.force_peer_path = True
+    grp.init_gpu([0] * shards, per, root=1)
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in range(3)]
+    grp.run(UPDATE_DELTA, params, 4)
+    grp.gather_begin()
+    grp.gather_wait()
+    maps = [grp.get_maps(c) for c in range(3)]
+    d, m = np.stack([x[0] for x in maps]), np.stack([x[1] for x in maps])
+    scales = np.array([[1 / p.tile_length[0], 1 / p.tile_length[1], p.displacement_scale, p.normal_scale] for p in params], np.float32)
+    rng = np.random.default_rng(3)
+    xz = rng.uniform(-300, 300, (2000, 2)).astype(np.float32)
+    got, want = grp.sample_surface(xz, scales), O.sample_surface(d, m, scales, xz)
+    for f in ("displacement", "gradient", "gradient_scaled", "foam", "spray_active", "gradient_fragment", "foam_fragment"):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+    grp.free()
+
+
+def test_group_argument_errors_and_bad_records():
+    L = _lib.load()
+    import ctypes as C
+    cfg = _lib.ow_group_config(map_size=256, num_devices=2, cascades_per_device=1, root=2)
+    g = C.c_void_p()
+    assert L.ow_group_create(C.byref(cfg), C.byref(g)) == _lib.OW_ERR_INVALID and not g
+    cfg.root = 0
+    cfg.device_ids[1] = 99
+    assert L.ow_group_create(C.byref(cfg), C.byref(g)) == _lib.OW_ERR_INVALID and b"device_ids[1]" in L.ow_last_error()
+    cfg.device_ids[1] = 0
+    cfg.map_size = 300
+    assert L.ow_group_create(C.byref(cfg), C.byref(g)) == _lib.OW_ERR_INVALID
+    grp = WaveGeneratorGroup()
+    grp.map_size = 256
+    grp.init_gpu([0, 0], 1)
+    with pytest.raises(_lib.OceanWavesError) as e:
+        grp.gather_wait()
+    assert e.value.status == _lib.OW_ERR_STATE
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in range(2)]
+    with pytest.raises(_lib.OceanWavesError) as e:   # all cascades' records, or none
+        grp.update_all(UPDATE_DELTA, params[:1])
+    assert e.value.status == _lib.OW_ERR_INVALID
+    grp.update_all(UPDATE_DELTA, params)
+    params[1].whitecap = float("nan")
+    t0 = [p.time for p in params]
+    with pytest.raises(_lib.OceanWavesError) as e:   # all shards' records are checked before any shard starts: nobody is a tick ahead
+        grp.update_all(UPDATE_DELTA, params)
+    assert e.value.status == _lib.OW_ERR_INVALID and "cascade 1" in str(e.value) and [p.time for p in params] == t0
+    grp.free()

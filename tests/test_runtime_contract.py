@@ -1,6 +1,6 @@
 """The C-ABI's contract around the hot path (include/ocean_waves.h, ABI version 2): the parameter records are COPIED by
 ow_update (wave_generator.gd:108 keeps an Array reference; a C / C# caller's memory is only borrowed during the call), bad
-records are refused before anything is launched, a cascade that could not be enqueued stays armed, the exported setters'
+records are refused on the way in (before anything of the caller's is changed, armed or launched), the exported setters'
 clamps (wave_cascade_parameters.gd:15,20) hold for a caller that has no setters, and a device-side wait that gives up is
 REPORTED through the status word instead of producing maps."""
 import ctypes as C
@@ -89,30 +89,48 @@ def test_live_edit_between_update_and_process_is_pushed_explicitly():
                 assert H.relmax(f32[..., c], want[..., c]) < H.TOL_F32, (i, name)
 
 
-def test_bad_record_is_refused_before_anything_is_launched_and_stays_armed():
+def test_bad_record_is_refused_on_the_way_in_and_leaves_no_trace():
+    """A record the kernels cannot take is refused by ow_update / ow_update_all / ow_set_cascade_params BEFORE anything changes:
+    no time advanced, no dirty flag consumed, nothing armed, nothing launched -- so the corrected array simply goes in again and the
+    context is never wedged on a stale armed copy (validation used to happen at enqueue, after the arm)."""
     n = 256
     gen, L = raw_gen(n, 2)
     arr = packed([0, 1])
     _lib.check(L.ow_update_all(gen.context, UPDATE_DELTA, arr, 2))
     gen.sync()
     before = [gen.get_maps(i) for i in range(2)]
-    arr[0].whitecap = float("nan")        # cascade 0 is enqueued AFTER cascade 1 (highest index first): nothing may run
-    assert L.ow_update_all(gen.context, UPDATE_DELTA, arr, 2) == _lib.OW_ERR_INVALID and b"non-finite" in L.ow_last_error()
+    t0 = [a.time for a in arr]
+    arr[0].whitecap = float("nan")
+    arr[1].should_generate_spectrum = 1
+    for call in (L.ow_update_all, L.ow_update):
+        assert call(gen.context, UPDATE_DELTA, arr, 2) == _lib.OW_ERR_INVALID and b"non-finite" in L.ow_last_error()
+        assert [a.time for a in arr] == t0 and arr[1].should_generate_spectrum == 1      # the caller's records are untouched
+        assert L.ow_cascades_remaining(gen.context) == 0                                 # nothing armed
+    assert _lib.check(L.ow_run(gen.context, UPDATE_DELTA, arr, 2, 0)) is None
+    assert L.ow_run(gen.context, UPDATE_DELTA, arr, 2, 5) == _lib.OW_ERR_INVALID and [a.time for a in arr] == t0
     gen.sync()
     for i in range(2):
         after = gen.get_maps(i)
         assert np.array_equal(after[0].view(np.uint16), before[i][0].view(np.uint16))
-    # ... and the one-cascade-per-frame drain: the bad cascade stays armed (ow_process does not drop it)
-    assert L.ow_cascades_remaining(gen.context) == 2
-    _lib.check(L.ow_process(gen.context))                                      # cascade 1 is fine
-    assert L.ow_process(gen.context) == _lib.OW_ERR_INVALID and L.ow_cascades_remaining(gen.context) == 1
-    fixed = ow_cascade_params()
-    _lib.check(L.ow_get_cascade_params(gen.context, 0, C.byref(fixed)))
-    fixed.whitecap = 0.5
-    _lib.check(L.ow_set_cascade_params(gen.context, 0, C.byref(fixed)))
-    _lib.check(L.ow_process(gen.context))
-    assert L.ow_cascades_remaining(gen.context) == 0
+    arr[0].tile_length[1] = 0.0
+    arr[0].whitecap = 0.5
+    assert L.ow_update(gen.context, UPDATE_DELTA, arr, 2) == _lib.OW_ERR_INVALID and b"tile_length" in L.ow_last_error()
+    arr[0].tile_length[1] = arr[0].tile_length[0]
+    # the corrected array: one tick, time advanced exactly once, and the one-cascade-per-frame drain works
+    _lib.check(L.ow_update(gen.context, UPDATE_DELTA, arr, 2))
+    assert [a.time for a in arr] == [t + UPDATE_DELTA for t in t0] and L.ow_cascades_remaining(gen.context) == 2
+    # a bad live edit is refused as well and leaves the armed copy as it was
+    bad, kept = ow_cascade_params(), ow_cascade_params()
+    _lib.check(L.ow_get_cascade_params(gen.context, 0, C.byref(bad)))
+    bad.wind_direction = float("inf")
+    assert L.ow_set_cascade_params(gen.context, 0, C.byref(bad)) == _lib.OW_ERR_INVALID
+    _lib.check(L.ow_get_cascade_params(gen.context, 0, C.byref(kept)))
+    assert kept.wind_direction == arr[0].wind_direction
+    while L.ow_cascades_remaining(gen.context):
+        _lib.check(L.ow_process(gen.context))
+    gen.sync()
     assert L.ow_update(gen.context, float("inf"), arr, 2) == _lib.OW_ERR_INVALID
+    assert L.ow_cascades_remaining(gen.context) == 0
 
 
 def test_setter_clamps_hold_for_a_caller_without_setters():
@@ -160,7 +178,11 @@ def test_a_rendezvous_that_gives_up_is_an_error_not_maps():
     with pytest.raises(_lib.OceanWavesError) as e:
         gen.sync()
     assert e.value.status == _lib.OW_ERR_HIP and "rendezvous" in str(e.value)
-    gen.sync()                                  # reported once
+    gen.sync()                                  # the status word is reported once ...
+    with pytest.raises(_lib.OceanWavesError):   # ... but the failure is sticky for what hands out maps, until they are recomputed
+        gen.get_maps(0)
+    with pytest.raises(_lib.OceanWavesError):
+        gen.get_maps_f32(0)
     gen.debug_inject_fault(1)
     gen.update_all(UPDATE_DELTA, params)
     with pytest.raises(_lib.OceanWavesError):   # every call that hands out maps checks, not only ow_sync
