@@ -8,6 +8,7 @@
 //
 // The reference issues six dispatches per cascade; here a batch of cascades is two launches.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -838,6 +839,98 @@ ow_status ow_get_device_ptrs(ow_context *c, void **disp, void **norm, size_t *st
     if (norm) *norm = c->buf.norm;
     if (stride) *stride = plane(c) * sizeof(ow::u16x4);
     return OW_OK;
+}
+
+// ---- zero-copy hand-off: dma-buf export of the two arrays, import of a foreign allocation (ocean_waves.h) ----
+ow_status ow_export_maps(ow_context *c, int32_t *disp_fd, int32_t *norm_fd, size_t *bytes_each) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    OW_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->layers * plane(c) * sizeof(ow::u16x4);
+    int fds[2] = {-1, -1};
+    void *ptrs[2] = {c->buf.disp, c->buf.norm};
+    for (int i = 0; i < 2; ++i) {
+        if ((i == 0 && !disp_fd) || (i == 1 && !norm_fd)) continue;
+        const hipError_t e = hipMemGetHandleForAddressRange(&fds[i], (hipDeviceptr_t)ptrs[i], bytes, hipMemRangeHandleTypeDmaBufFd, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (fds[0] >= 0) close(fds[0]);
+            return fail(OW_ERR_HIP, "hipMemGetHandleForAddressRange (dma-buf export of the %s array, %zu bytes) failed: %s", i ? "normal" : "displacement",
+                        bytes, hipGetErrorString(e));
+        }
+    }
+    if (disp_fd) *disp_fd = fds[0];
+    if (norm_fd) *norm_fd = fds[1];
+    if (bytes_each) *bytes_each = bytes;
+    return OW_OK;
+}
+
+struct ow_imported {
+    hipExternalMemory_t ext = nullptr;
+    void *ptr = nullptr;
+    int device = 0;
+};
+
+ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_imported **out, void **device_ptr) {
+    if (!out || !device_ptr) return fail(OW_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *device_ptr = nullptr;
+    if (fd < 0 || bytes == 0) return fail(OW_ERR_INVALID, "bad file descriptor or size");
+    int ndev = 0, caller_dev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(OW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    OW_HIP(hipGetDevice(&caller_dev));
+    const int dev = device_id < 0 ? caller_dev : device_id;
+    if (dev >= ndev) return fail(OW_ERR_INVALID, "device_id %d >= device count %d", dev, ndev);
+    struct DeviceRestore {
+        int dev;
+        ~DeviceRestore() { (void)hipSetDevice(dev); }
+    } restore{caller_dev};
+    OW_HIP(hipSetDevice(dev));
+    const int own = dup(fd);  // the import consumes a descriptor; the caller's stays the caller's
+    if (own < 0) return fail(OW_ERR_INVALID, "dup(%d) failed", fd);
+    hipExternalMemoryHandleDesc hd;
+    std::memset(&hd, 0, sizeof(hd));
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+    hd.handle.fd = own;
+    hd.size = bytes;
+    hipExternalMemory_t ext = nullptr;
+    hipError_t e = hipImportExternalMemory(&ext, &hd);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        close(own);
+        return fail(OW_ERR_HIP, "hipImportExternalMemory(fd, %zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    hipExternalMemoryBufferDesc bd;
+    std::memset(&bd, 0, sizeof(bd));
+    bd.offset = 0;
+    bd.size = bytes;
+    void *ptr = nullptr;
+    e = hipExternalMemoryGetMappedBuffer(&ptr, ext, &bd);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipDestroyExternalMemory(ext);
+        return fail(OW_ERR_HIP, "hipExternalMemoryGetMappedBuffer failed: %s", hipGetErrorString(e));
+    }
+    ow_imported *im = new (std::nothrow) ow_imported();
+    if (!im) {
+        (void)hipDestroyExternalMemory(ext);
+        return fail(OW_ERR_NOMEM, "out of host memory");
+    }
+    im->ext = ext;
+    im->ptr = ptr;
+    im->device = dev;
+    *out = im;
+    *device_ptr = ptr;
+    return OW_OK;
+}
+
+void ow_release_buffer(ow_imported *im) {
+    if (!im) return;
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
+    (void)hipSetDevice(im->device);
+    (void)hipDestroyExternalMemory(im->ext);
+    delete im;
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }
 
 ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {

@@ -297,6 +297,27 @@ ow_status ow_group_get_maps(ow_group *group, int32_t cascade, void *displacement
 ow_status ow_group_sample_surface(ow_group *group, const float *world_xz, int32_t count, const float *map_scales, int32_t num_cascades,
                                   ow_surface_sample *out);
 
+/* ---- zero-copy hand-off: the maps as dma-buf file descriptors ------------------------------------------------------ */
+
+/* The reference's outputs are never copied: its compute shaders write the two array textures on the engine's own
+ * RenderingDevice and the water shaders sample them in place (wave_generator.gd:19,34-35; README.md:85 -- the PCIe copy is
+ * what killed the author's asynchronous experiment).  Across APIs the same needs shared memory, and this is the half of it
+ * that is HIP's:
+ *   ow_export_maps   : the context's displacement / normal arrays as two dma-buf file descriptors (the caller closes them).
+ *                      A Vulkan consumer imports them with VkImportMemoryFdInfoKHR (VK_EXT_external_memory_dma_buf) into a
+ *                      linear RGBA16F buffer / image of N x N x layers; another HIP process or context with ow_import_buffer.
+ *                      Needs arrays the context allocated itself (or caller memory that is a whole page-aligned allocation).
+ *   ow_import_buffer : the other direction -- an fd exported elsewhere (VK_KHR_external_memory_fd from the engine's device,
+ *                      or ow_export_maps in another process) becomes a device pointer on `device_id`, e.g. to be handed to
+ *                      ow_create as ow_config.displacement_map / normal_map, so that the kernels write the engine's memory.
+ *                      The fd stays the caller's (it is duplicated); ow_release_buffer unmaps.
+ * Synchronisation stays with the caller (ow_sync / ow_readback-style fences before the consumer samples), as it does between
+ * any two queues. */
+typedef struct ow_imported ow_imported;
+ow_status ow_export_maps(ow_context *ctx, int32_t *displacement_fd, int32_t *normal_fd, size_t *bytes_each);
+ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_imported **out, void **device_ptr);
+void ow_release_buffer(ow_imported *imported);
+
 /* ---- parity / debug ------------------------------------------------------------------------------ */
 
 /* 8 FP32 channels per texel before FP16 quantisation: [hx, hy, hz, grad_x, grad_y, dhx_dx, foam, jacobian],
