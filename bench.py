@@ -263,11 +263,18 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     unmerged = None
     if world == 1 and not args.no_unmerged:
         gen = make_generator(tick_groups=False)
+        # fresh parameter objects: their dirty flags make THIS context generate its spectra (the first context consumed the old
+        # objects' flags -- a context fed with them would run on all-zero spectra, and zeros run measurably FASTER: 52.0 against
+        # 55.4 us per tick at 1024^2 x 4, less switching power, higher clock; round 3 fell for that once)
+        params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
+        disp.zero_()
+        torch.cuda.synchronize()
         gen.update_all(UPDATE_DELTA, params)
         gen.run(UPDATE_DELTA, params, max(50, args.warmup))
         gen.sync()
         unmerged, unmerged_samples = timed(0)
         assert gen.last_kernel_family() == family, (gen.last_kernel_family(), family)
+        assert bool(torch.isfinite(disp[:C].float()).all()) and float(disp[:C].float().abs().max()) > 0.0  # real maps, not zeros
         gen.free()
     if rank != 0:
         return None

@@ -95,7 +95,7 @@ SIGNATURES = {
     "ow_group_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ow_group_sample_surface": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ow_export_maps": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_size_t)]),
-    "ow_import_buffer": (C.c_int, [C.c_int32, C.c_int32, C.c_size_t, _P(C.c_void_p), _P(C.c_void_p)]),
+    "ow_import_buffer": (C.c_int, [C.c_int32, C.c_int32, C.c_size_t, C.c_size_t, _P(C.c_void_p), _P(C.c_void_p)]),
     "ow_release_buffer": (None, [C.c_void_p]),
     "ow_last_error": (C.c_char_p, []),
     "ow_abi_version": (C.c_int32, []),

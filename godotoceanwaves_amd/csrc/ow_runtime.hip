@@ -211,6 +211,13 @@ ow_status ensure_scratch(ow_context *c, int slots) {
     return OW_OK;
 }
 
+// The runtime carves allocations below 2 MiB out of shared 2 MiB buffer objects, and a dma-buf always covers the whole object
+// (measured: scripts/dmabuf_probe.py -- an import of the second 1 MiB allocation saw the first one's bytes).  The two output arrays
+// are therefore allocated in whole multiples of 2 MiB: each is a buffer object of its own and ow_export_maps' descriptors map it
+// from offset 0.
+constexpr size_t kExportGranule = (size_t)2 << 20;
+size_t exportable_bytes(size_t bytes) { return (bytes + kExportGranule - 1) / kExportGranule * kExportGranule; }
+
 constexpr size_t kMaxTimedBatches = 4096;
 
 ow_status collect_timing(ow_context *c) {
@@ -485,13 +492,13 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
-        OW_ALLOC(c->buf.disp, L * pl * sizeof(ow::u16x4));            // R16G16B16A16_SFLOAT (:34)
+        OW_ALLOC(c->buf.disp, exportable_bytes(L * pl * sizeof(ow::u16x4)));  // R16G16B16A16_SFLOAT (:34)
         c->own_disp = true;
     }
     if (cfg->normal_map) {
         c->buf.norm = (ow::u16x4 *)cfg->normal_map;
     } else {
-        OW_ALLOC(c->buf.norm, L * pl * sizeof(ow::u16x4));            // (:35)
+        OW_ALLOC(c->buf.norm, exportable_bytes(L * pl * sizeof(ow::u16x4)));  // (:35)
         c->own_norm = true;
     }
     OW_ALLOC(c->buf.foam, L * pl * sizeof(uint16_t));                 // FP16 foam state in pass-2 lane order
@@ -848,8 +855,20 @@ ow_status ow_export_maps(ow_context *c, int32_t *disp_fd, int32_t *norm_fd, size
     const size_t bytes = (size_t)c->layers * plane(c) * sizeof(ow::u16x4);
     int fds[2] = {-1, -1};
     void *ptrs[2] = {c->buf.disp, c->buf.norm};
+    const bool own[2] = {c->own_disp, c->own_norm};
     for (int i = 0; i < 2; ++i) {
         if ((i == 0 && !disp_fd) || (i == 1 && !norm_fd)) continue;
+        if (!own[i]) {  // caller-owned memory: exportable only if it is a whole buffer object (see exportable_bytes)
+            void *base = nullptr;
+            size_t range = 0;
+            if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &range, (hipDeviceptr_t)ptrs[i]) != hipSuccess || base != ptrs[i] || range < kExportGranule ||
+                ((uintptr_t)base & (kExportGranule - 1)) != 0) {
+                (void)hipGetLastError();
+                if (fds[0] >= 0) close(fds[0]);
+                return fail(OW_ERR_STATE, "the caller-owned %s array is not the start of an allocation of at least 2 MiB: a dma-buf covers whole buffer "
+                                          "objects, so the descriptor would not map the array from offset 0", i ? "normal" : "displacement");
+            }
+        }
         const hipError_t e = hipMemGetHandleForAddressRange(&fds[i], (hipDeviceptr_t)ptrs[i], bytes, hipMemRangeHandleTypeDmaBufFd, 0);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -870,7 +889,7 @@ struct ow_imported {
     int device = 0;
 };
 
-ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_imported **out, void **device_ptr) {
+ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t offset, size_t bytes, ow_imported **out, void **device_ptr) {
     if (!out || !device_ptr) return fail(OW_ERR_INVALID, "null argument");
     *out = nullptr;
     *device_ptr = nullptr;
@@ -891,18 +910,18 @@ ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_impor
     std::memset(&hd, 0, sizeof(hd));
     hd.type = hipExternalMemoryHandleTypeOpaqueFd;
     hd.handle.fd = own;
-    hd.size = bytes;
+    hd.size = offset + bytes;
     hipExternalMemory_t ext = nullptr;
     hipError_t e = hipImportExternalMemory(&ext, &hd);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         close(own);
-        return fail(OW_ERR_HIP, "hipImportExternalMemory(fd, %zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return fail(OW_ERR_HIP, "hipImportExternalMemory(fd, %zu bytes) failed: %s", offset + bytes, hipGetErrorString(e));
     }
     hipExternalMemoryBufferDesc bd;
     std::memset(&bd, 0, sizeof(bd));
-    bd.offset = 0;
-    bd.size = bytes;
+    bd.offset = 0;             // the window is applied to the mapped pointer below: given a non-zero offset, this runtime's
+    bd.size = offset + bytes;  // GetMappedBuffer did not return the window's bytes (round 3, first version of tests/test_interop.py)
     void *ptr = nullptr;
     e = hipExternalMemoryGetMappedBuffer(&ptr, ext, &bd);
     if (e != hipSuccess) {
@@ -919,7 +938,7 @@ ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_impor
     im->ptr = ptr;
     im->device = dev;
     *out = im;
-    *device_ptr = ptr;
+    *device_ptr = static_cast<char *>(ptr) + offset;
     return OW_OK;
 }
 

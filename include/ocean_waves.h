@@ -306,16 +306,20 @@ ow_status ow_group_sample_surface(ow_group *group, const float *world_xz, int32_
  *   ow_export_maps   : the context's displacement / normal arrays as two dma-buf file descriptors (the caller closes them).
  *                      A Vulkan consumer imports them with VkImportMemoryFdInfoKHR (VK_EXT_external_memory_dma_buf) into a
  *                      linear RGBA16F buffer / image of N x N x layers; another HIP process or context with ow_import_buffer.
- *                      Needs arrays the context allocated itself (or caller memory that is a whole page-aligned allocation).
+ *                      A dma-buf covers a whole buffer object and the runtime packs allocations below 2 MiB into shared ones, so
+ *                      the context allocates its arrays in multiples of 2 MiB (each descriptor maps its array from offset 0);
+ *                      caller-owned arrays are exported only if they start a 2 MiB-aligned allocation of at least 2 MiB
+ *                      (OW_ERR_STATE otherwise).
  *   ow_import_buffer : the other direction -- an fd exported elsewhere (VK_KHR_external_memory_fd from the engine's device,
- *                      or ow_export_maps in another process) becomes a device pointer on `device_id`, e.g. to be handed to
+ *                      or ow_export_maps in another process) becomes a device pointer to bytes [offset, offset + bytes) of that
+ *                      memory on `device_id`, e.g. to be handed to
  *                      ow_create as ow_config.displacement_map / normal_map, so that the kernels write the engine's memory.
  *                      The fd stays the caller's (it is duplicated); ow_release_buffer unmaps.
  * Synchronisation stays with the caller (ow_sync / ow_readback-style fences before the consumer samples), as it does between
  * any two queues. */
 typedef struct ow_imported ow_imported;
 ow_status ow_export_maps(ow_context *ctx, int32_t *displacement_fd, int32_t *normal_fd, size_t *bytes_each);
-ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t bytes, ow_imported **out, void **device_ptr);
+ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t offset, size_t bytes, ow_imported **out, void **device_ptr);
 void ow_release_buffer(ow_imported *imported);
 
 /* ---- parity / debug ------------------------------------------------------------------------------ */

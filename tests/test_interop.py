@@ -61,7 +61,7 @@ def test_exported_maps_are_the_live_arrays_in_this_and_in_a_second_process():
         handles = []
         for fd, which in ((dfd, 0), (nfd, 1)):
             im, ptr = C.c_void_p(), C.c_void_p()
-            _lib.check(L.ow_import_buffer(-1, fd, nbytes, C.byref(im), C.byref(ptr)))
+            _lib.check(L.ow_import_buffer(-1, fd, 0, nbytes, C.byref(im), C.byref(ptr)))
             handles.append((im, ptr, which))
         for tick in range(2):  # the mapping is the live array: later ticks show up without any copy
             for im, ptr, which in handles:
@@ -78,7 +78,7 @@ def test_exported_maps_are_the_live_arrays_in_this_and_in_a_second_process():
                  "h = C.CDLL('libamdhip64.so'); h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]\n"
                  "for fd in (int(sys.argv[1]), int(sys.argv[2])):\n"
                  "    im, ptr = C.c_void_p(), C.c_void_p()\n"
-                 "    _lib.check(L.ow_import_buffer(0, fd, int(sys.argv[3]), C.byref(im), C.byref(ptr)))\n"
+                 "    _lib.check(L.ow_import_buffer(0, fd, 0, int(sys.argv[3]), C.byref(im), C.byref(ptr)))\n"
                  "    out = np.empty(int(sys.argv[3]), np.uint8)\n"
                  "    assert h.hipMemcpy(out.ctypes.data, ptr, out.size, 2) == 0\n"
                  "    print(hashlib.sha1(out.tobytes()).hexdigest())\n"
@@ -107,8 +107,8 @@ def test_kernels_write_into_imported_foreign_memory():
     dfd, nfd, nbytes = export(owner)
     try:
         im_d, p_d, im_n, p_n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _lib.check(L.ow_import_buffer(0, dfd, nbytes, C.byref(im_d), C.byref(p_d)))
-        _lib.check(L.ow_import_buffer(0, nfd, nbytes, C.byref(im_n), C.byref(p_n)))
+        _lib.check(L.ow_import_buffer(0, dfd, 0, nbytes, C.byref(im_d), C.byref(p_d)))
+        _lib.check(L.ow_import_buffer(0, nfd, 0, nbytes, C.byref(im_n), C.byref(p_n)))
         gen, params = make(n, ids, external_maps=(p_d.value, p_n.value))
         ref, rparams = make(n, ids)
         for g, p in ((gen, params), (ref, rparams)):
@@ -130,14 +130,43 @@ def test_kernels_write_into_imported_foreign_memory():
 def test_argument_errors():
     L = _lib.load()
     im, ptr = C.c_void_p(), C.c_void_p()
-    assert L.ow_import_buffer(0, -1, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
-    assert L.ow_import_buffer(0, 0, 0, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
-    assert L.ow_import_buffer(99, 0, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
+    assert L.ow_import_buffer(0, -1, 0, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
+    assert L.ow_import_buffer(0, 0, 0, 0, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
+    assert L.ow_import_buffer(99, 0, 0, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_INVALID
     r, w = os.pipe()  # a descriptor that is no dma-buf: refused by the runtime, reported, nothing leaked
     try:
-        assert L.ow_import_buffer(0, r, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_HIP and not im
+        assert L.ow_import_buffer(0, r, 0, 4096, C.byref(im), C.byref(ptr)) == _lib.OW_ERR_HIP and not im
     finally:
         os.close(r)
         os.close(w)
     assert L.ow_export_maps(None, None, None, None) == _lib.OW_ERR_INVALID
     L.ow_release_buffer(None)
+
+
+def test_offset_import_and_refusal_of_packed_caller_memory():
+    """an import may map a window of the exported object (one layer here); caller-owned arrays that are carved out of a larger
+    allocation cannot be exported unambiguously (a dma-buf covers the whole buffer object) and are refused"""
+    import torch
+    L = _lib.load()
+    n = 256
+    gen, params = make(n, [0, 1, 2])
+    gen.run(UPDATE_DELTA, params, 2)
+    gen.sync()
+    dfd, nfd, nbytes = export(gen)
+    try:
+        layer = n * n * 8
+        im, ptr = C.c_void_p(), C.c_void_p()
+        _lib.check(L.ow_import_buffer(0, nfd, 2 * layer, layer, C.byref(im), C.byref(ptr)))
+        got = read_device(ptr, layer).view(np.uint16).reshape(n, n, 4)
+        assert np.array_equal(got, gen.get_maps(2)[1].view(np.uint16))
+        L.ow_release_buffer(im)
+    finally:
+        os.close(dfd)
+        os.close(nfd)
+    arena = torch.zeros(6 << 20, dtype=torch.uint8, device="cuda")   # the caller's own arena: the maps sit 1 MiB into it
+    base = arena.data_ptr() + (1 << 20)
+    packed, _ = make(n, [0, 1], external_maps=(base, base + 2 * n * n * 8))
+    d, m, nb = C.c_int32(-1), C.c_int32(-1), C.c_size_t()
+    assert L.ow_export_maps(packed.context, C.byref(d), C.byref(m), C.byref(nb)) == _lib.OW_ERR_STATE and b"whole buffer" in L.ow_last_error()
+    assert d.value == -1 and m.value == -1
+    packed.free()
