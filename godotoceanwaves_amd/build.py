@@ -20,7 +20,7 @@ UNITS = {
     "ow_consumer.hip": ["-ffp-contract=off"],
     "ow_group.hip": [],
 }
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():

@@ -22,7 +22,6 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/ocean_waves.h"
 #include "ow_internal.h"
 #include "ow_kernels.h"
 

@@ -2,18 +2,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The library is built with -fvisibility=hidden: only what include/ocean_waves.h declares is exported.
+#pragma GCC visibility push(default)
 #include "../../include/ocean_waves.h"
+#pragma GCC visibility pop
 
 namespace ow {
 
 // sets the calling thread's ow_last_error() text (printf-style) and returns `st`
-__attribute__((visibility("hidden"))) ow_status fail(ow_status st, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+ow_status fail(ow_status st, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // replaces the calling thread's ow_last_error() text (a group hands a worker thread's message to its caller)
-__attribute__((visibility("hidden"))) void set_last_error(const char *message);
+void set_last_error(const char *message);
 // every record finite, tile_length positive, time + delta finite (ow_runtime.hip; sets the error text)
-__attribute__((visibility("hidden"))) ow_status validate_records(const ow_cascade_params *params, int count, double delta);
+ow_status validate_records(const ow_cascade_params *params, int count, double delta);
 // the context's device status word without synchronising (ow_runtime.hip)
-__attribute__((visibility("hidden"))) ow_status poll_status(ow_context *c);
+ow_status poll_status(ow_context *c);
 
 }  // namespace ow
 

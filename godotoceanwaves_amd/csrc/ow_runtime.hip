@@ -19,7 +19,6 @@
 #include <string>
 #include <vector>
 
-#include "../../include/ocean_waves.h"
 #include "ow_internal.h"
 #include "ow_kernels.h"
 #include "ow_tables.h"

@@ -4,11 +4,12 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/godotoceanwaves_amd/csrc; name=$1; shift
 out=$C/build/variants; mkdir -p $out/$name
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -Wno-unused-function"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -fvisibility=hidden -Wno-unused-function"
 hipcc $F "$@" -c $C/ow_frame.hip -o $out/$name/ow_frame.o &
 hipcc $F "$@" -ffp-contract=off -c $C/ow_spectrum.hip -o $out/$name/ow_spectrum.o &
 hipcc $F "$@" -c $C/ow_runtime.hip -o $out/$name/ow_runtime.o &
 hipcc $F "$@" -ffp-contract=off -c $C/ow_consumer.hip -o $out/$name/ow_consumer.o &
+hipcc $F "$@" -c $C/ow_group.hip -o $out/$name/ow_group.o &
 wait
 hipcc --offload-arch=gfx950 -shared -o $out/$name.so $out/$name/*.o
 echo $out/$name.so

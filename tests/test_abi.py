@@ -31,6 +31,9 @@ def test_header_symbols_all_exported(lib):
     exported = set(re.findall(r" T (ow_[a-z0-9_]+)", out))
     assert set(syms) <= exported, sorted(set(syms) - exported)
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    # ... and nothing else: the library is built with -fvisibility=hidden, its C++ internals (launchers, kernels' host stubs) stay inside
+    other = [l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith("ow_")]
+    assert other == [], other
 
 
 def test_header_is_plain_c():
