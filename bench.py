@@ -160,11 +160,13 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         sync_all()
         t0 = time.perf_counter()
         if gat is not None and gather_every > 0:
+            # a pipelined consumer: every chunk of k ticks BEGINS by shipping the maps as they stand (the previous chunk's last tick;
+            # snapshot in stream order, bytes on the side stream), so each gather has its k ticks of compute to hide under
             done = 0
             while done < args.steps:
                 k = min(gather_every, args.steps - done)
-                gen.run(UPDATE_DELTA, params, k)
                 gat.begin()
+                gen.run(UPDATE_DELTA, params, k)
                 done += k
             gat.wait()  # the last gather's bytes have arrived
         else:
@@ -213,8 +215,13 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             sync_all()
             gather_probe = max_over_ranks(time.perf_counter() - t0) / 5
             gather_every = max(1, int(math.ceil(1.25 * gather_probe / max(tick_probe, 1e-9))))  # 25 % slack: the links must never be the queue
-            cadence = {"policy": "auto: smallest k with 1.25 x gather time <= k ticks", "tick_probe_ms": round(tick_probe * 1e3, 5),
-                       "gather_probe_ms": round(gather_probe * 1e3, 4)}
+            cadence = {"policy": "auto: smallest k with 1.25 x gather time <= k ticks, at most --steps (one gather per timed region at least)",
+                       "tick_probe_ms": round(tick_probe * 1e3, 5), "gather_probe_ms": round(gather_probe * 1e3, 4), "uncapped_every_ticks": gather_every}
+            # a timed region is EXACTLY --steps ticks between two synchronisations: it cannot hold a cadence longer than itself.  With
+            # fewer steps than the links need per gather the region ships one gather, begun at its start and overlapped with its ticks --
+            # region time = max(compute, gather), stated as such in the line (`gather.bound`)
+            gather_every = min(gather_every, args.steps)
+        gather_every = max(0, min(gather_every, args.steps)) if gather_every else 0
 
     # ---- timed regions ----
     elapsed, samples = timed(gather_every)
@@ -241,7 +248,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     # ---- per-kernel durations, in situ: during `probe` further ticks every launch carries start/stop HIP events bound
     #      to its own dispatch packet on the generator's stream (hipExtLaunchKernel): begin -> end of the kernel itself,
     #      the quantity a rocprofv3 kernel trace reports ----
-    probe = max(50, min(400, args.steps))
+    probe = 400  # (independent of --steps: a 50-tick probe right after an idle moment measured the clock ramp, 33 us where 400 ticks give 27.7)
     merged = launch_mode in MERGED_KERNEL
     gl_ms = gl_n = 0
     if merged:  # ow_run's merged launches (tick groups / tick pairs), each timed on its own
@@ -250,6 +257,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         gen.sync()
         gl_ms, gl_n = gen.timing_read_launches()
         gen.timing(False)
+    gen.run(UPDATE_DELTA, params, 200)  # untimed: clocks back up after the host-side bookkeeping above
     gen.timing(True)
     gen.run(UPDATE_DELTA, params, probe)
     gen.sync()
@@ -407,6 +415,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         out["final_gather_ms"] = round(gather_ms, 3)
         out["gather_bytes"] = {"sent_per_rank": gat.bytes_sent, "received_rank0": gat.bytes_received}
         out["gather"] = {"mode": args.gather, "every_ticks": gather_every, "overlap": not args.no_overlap, **(cadence or {}),
+                         "bound": ("links: --steps is shorter than the cadence the links sustain, the region holds one gather and lasts max(compute, gather)"
+                                   if (cadence and cadence["uncapped_every_ticks"] > args.steps) else "compute: every gather hides under its chunk of ticks"),
                          # what the links deliver: bytes into the consumer per gather / the time between gathers in the timed region
                          "gathers_per_s": round(args.steps / max(1, gather_every) / elapsed, 2) if gather_every else None,
                          "root_inbound_gbps": round(gat.bytes_received * (world - 1) / world * (args.steps / max(1, gather_every)) / elapsed / 1e9, 2)

@@ -137,18 +137,29 @@ constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
-    const int cap = (int)(kPairTexels / ((size_t)c->n * c->n));
-    if (cap < 1 || count < 1 || !ow::tick_groups_supported(c->n)) return 0;
-    const int B = (count + cap - 1) / cap;
-    for (int b = 0, left = count; b < B; ++b) {
-        sizes[b] = (left + (B - b) - 1) / (B - b);
-        left -= sizes[b];
-        if (ow::kernel_family(c->n, sizes[b], c->kernel_mode) != 3) return 0;
+    size_t pair_texels = kPairTexels;
+    if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS")) pair_texels = (size_t)atol(e) << 20;  // measurement knob: batch size of the tick pairs, in Mi texels
+    const size_t pl = (size_t)c->n * c->n;
+    if (count < 1 || !ow::tick_groups_supported(c->n)) return 0;
+    // Where two full-size batches of intermediate next to the spectra do not fit the Infinity Cache (1024^2 x 8: 96 + 2 x 80 MiB), batches
+    // of half the size do (96 + 2 x 40): every launch is then one full round of blocks (256 of each pass at 1024^2) instead of two --
+    // measured (round 3, same process, us per tick, one launch per pass | pairs of 2-cascade batches): 1024^2 x 8 115.1 | 113.3; the full-size
+    // batches stay where they fit (x 4: 54.5 against 56.7 in half-size batches; x 6: 85.3 | 85.0).
+    for (int cap = (int)(pair_texels / pl); cap >= 1; cap /= 2) {
+        const int B = (count + cap - 1) / cap;
+        bool family_ok = true;
+        for (int b = 0, left = count; b < B; ++b) {
+            sizes[b] = (left + (B - b) - 1) / (B - b);
+            left -= sizes[b];
+            family_ok = family_ok && ow::kernel_family(c->n, sizes[b], c->kernel_mode) == 3;
+        }
+        if (!family_ok) return 0;  // (smaller batches would leave the compact family as well)
+        // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
+        const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
+        if (B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
+        return B;
     }
-    const size_t pl = (size_t)c->n * c->n;  // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
-    const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
-    if (B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) return 0;
-    return B;
+    return 0;
 }
 // ticks per launch of a run of `count` cascades in tick groups: four; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick)
 // -- deeper groups pay only there; never more than fits kGroupScratchBytes twice over (the intermediates are double-buffered)

@@ -98,7 +98,7 @@ typedef struct ow_config {
  *    consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
  *    (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled
  *    by several (k_tick_group_c_lp);
- *  - TICK PAIRS, the compact family (1024^2 x 2 .. 7, 512^2 x 7 ..; map sizes up to 1024^2): the run is a stream of batches of at most 4 Mi
+ *  - TICK PAIRS, the compact family (1024^2 x 2 .. 8, 512^2 x 7 ..; map sizes up to 1024^2): the run is a stream of batches of at most 4 Mi
  *    texels and one launch does pass 2 of one batch and pass 1 of the next -- the same cascades one tick later, or the tick's other
  *    cascades (k_tick_pair_c).
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).

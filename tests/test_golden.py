@@ -1,5 +1,6 @@
 """The HIP path against the committed golden vectors (tests/golden/*.npz = outputs of the reference's own
-shaders, see tests/golden/make_golden.py).  Tolerances: RGBA16F maps <= 1 fp16 ulp, foam (recurrent FP16 state)
+shaders, see tests/golden/make_golden.py).  Tolerances: RGBA16F maps <= 1 fp16 ulp + 1e-5 of the channel's maximum (helpers.fp16_close:
+the floor is what lets "one ulp" hold near zero crossings, where the ulp shrinks with the value and an FP32 transform error does not), foam (recurrent FP16 state)
 within one FP16 step of [0,1], fft_buffer after pass 1 <= 1e-5 and spectrum <= 2e-5 max-norm relative."""
 import glob
 import os
@@ -17,7 +18,7 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)
 
 @pytest.mark.parametrize("kernels", [None, "standard"], ids=["runtime_default", "standard"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-def test_hip_path_matches_reference_shader_outputs(path, kernels):
+def test_hip_path_within_one_fp16_ulp_plus_1e5_of_channel_max_of_reference_shader_outputs(path, kernels):
     """kernels=None is what a caller gets: the runtime's own choice for the batch (layer-parallel / compact-intermediate
     kernels from 256^2 on -- the family the headline numbers are measured on), held against bytes the reference's own
     shaders produced (at 1024^2 too: ref_n1024_*.npz).  The compact intermediate has no counterpart in the reference's
@@ -50,7 +51,7 @@ def test_hip_path_matches_reference_shader_outputs(path, kernels):
 
 
 @pytest.mark.parametrize("path", [p for p in GOLDEN if "n1024" in p or "n512" in p], ids=lambda p: os.path.basename(p))
-def test_large_batch_compact_kernels_match_reference_shader_outputs(path):
+def test_large_batch_compact_kernels_within_one_fp16_ulp_plus_1e5_of_channel_max_of_reference_shader_outputs(path):
     """k_pass1c / k_pass2c proper (the pair the 1024^2 x 4 headline runs on, not their layer-parallel form that a lone
     cascade would get): the fixture's cascade is computed as one of four in a single batch."""
     z = np.load(path)
@@ -84,7 +85,7 @@ def _check_maps(gen, layer, z):
 
 @pytest.mark.parametrize("path", [p for p in GOLDEN if p.endswith("_f3.npz") and ("n1024" in p or "n512" in p)], ids=lambda p: os.path.basename(p))
 @pytest.mark.parametrize("batch", ["alone", "full"])
-def test_merged_launches_of_ow_run_match_reference_shader_outputs(path, batch):
+def test_merged_launches_of_ow_run_within_one_fp16_ulp_plus_1e5_of_channel_max_of_reference_shader_outputs(path, batch):
     """ow_run(3) = one ordinary tick + two ticks that go out merged across ticks; what it leaves behind is held against the bytes the
     reference's own shaders produced after three updates.  "alone": the fixture's cascade on its own -- the tick groups
     (k_tick_group_c_lp); "full": as one of a batch of the compact family (1024^2 x 4, 512^2 x 8) -- the tick pairs (k_tick_pair_c),
