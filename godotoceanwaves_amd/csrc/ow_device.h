@@ -88,7 +88,20 @@ constexpr int plan_region_cplx(int N) { return N + N / 16 + 4; }
 constexpr int plan_tw_size(int N, int j) { return (plan_R(N, j) - 1) * plan_m(N, j); }
 constexpr int plan_tw_off(int N, int j) { return j == 0 ? 0 : (j == 1 ? plan_tw_size(N, 0) : plan_tw_size(N, 0) + plan_tw_size(N, 1)); }
 constexpr int plan_tw_total(int N) { return plan_tw_off(N, plan_S(N) - 1); }
-constexpr int lds_slot(int e) { return e + (e >> 4); }
+// Padded LDS slot of element e of a row's exchange image: e + (e >> 5).  LDS has 64 banks of 4 bytes; a wave's ds_read_b64 /
+// ds_write_b64 is served in two halves of 32 lanes, each lane taking a bank pair, so an access is conflict-free when the 32 slots of a
+// half are distinct mod 32.  Stage-0 writes (element 16 t + k over lanes t) see 16 (t & 1) + (t >> 1) + k, stage-1 reads (element
+// q + 16 p + 64 i over lanes (q, p)) see q + 16 (p & 1) + const: both permutations of 0..31.  Rounds 1-2 used e + (e >> 4), under which
+// the two 16-lane runs of a stage-1 read overlap in one slot (q = 15 of p = 0 against q = 0 of p = 1 after the wrap), so that every such
+// read took two passes per half instead of one -- the 14 % of LDS-active cycles that profiles/r02_pmc_sq_tick_pairs_1024x4.txt counts as
+// bank conflicts (tools/lds_bank_model.py reproduces the figure and walks every plan: 512 and 1024 are conflict-free now, 128 loses the
+// conflicts of its stage-0 writes, 256 -- four rows per wave, the row regions' offset enters the pattern -- is unchanged; at 2048, with
+// three LDS stages, no padding frees all four access kinds because the two writes and the two reads constrain the same weights, and this
+// one leaves the stage-1 write at two passes: 320 passes per row transform instead of 384).
+#ifndef OW_LDS_PAD_SHIFT
+#define OW_LDS_PAD_SHIFT 5  // (4 = the padding of rounds 1-2, kept for A/B builds: scripts/build_variant.sh pad4 -DOW_LDS_PAD_SHIFT=4)
+#endif
+constexpr int lds_slot(int e) { return e + (e >> OW_LDS_PAD_SHIFT); }
 // whole workgroup: [twiddle table][8 x row region]
 constexpr int plan_wg_lds_cplx(int N) { return plan_region_cplx(N) * kWgRows + plan_tw_total(N); }
 
@@ -228,8 +241,8 @@ OW_DEV void fft_stage_compute(cplx *d, int t, const cplx *__restrict__ tw) {
 
 // LDS slot of the element a lane writes after / reads before a stage.  For every plan used here the slot is
 // affine in (b, k): slot(t, b, k) = slot(t, 0, 0) + [slot(0, b, k) - slot(0, 0, 0)], because T is a multiple of
-// 16 (or, at N = 128, the lane index stays below 16), so the padding term e >> 4 never carries across the lane
-// part.  The lane part is computed once per stage; the (b, k) part is a compile-time DS offset.
+// 16 (or, at N = 128, the lane index stays below 16): the lane part and the (b, k) part of the element index occupy disjoint
+// bits, and e + (e >> 5) is additive over numbers with disjoint bits.  The lane part is computed once per stage; the (b, k) part is a compile-time DS offset.
 template <int N, int J>
 constexpr int wr_slot(int t, int b, int k) {
     const int R = plan_R(N, J), T = plan_T(N), s = plan_s(N, J);
