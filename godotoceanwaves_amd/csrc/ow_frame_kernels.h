@@ -51,6 +51,10 @@ __device__ __forceinline__ void lds_barrier() {
 // rendezvous through two LDS words (each wave publishes a monotonically increasing epoch after its own LDS traffic has
 // completed, and polls its partner's) instead of an s_barrier, which would put all 16 waves of the block in lockstep
 // at every exchange although only pairs exchange data.
+// polls of the partner's epoch word before the waiting wave starts to sleep between polls (measured, round 3: see DESIGN.md section 8)
+#ifndef OW_ROWSYNC_FREE_POLLS
+#define OW_ROWSYNC_FREE_POLLS 0
+#endif
 template <int N>
 struct RowSync {
     typedef __attribute__((address_space(3))) int lds_int;
@@ -88,7 +92,7 @@ struct RowSync {
                 unsigned long long t0 = 0;
                 bool gave_up = false;
                 while (__builtin_amdgcn_readfirstlane(*partner) < epoch) {
-                    __builtin_amdgcn_s_sleep(1);
+                    if (spin >= OW_ROWSYNC_FREE_POLLS) __builtin_amdgcn_s_sleep(1);
                     if ((++spin & 255) == 0) {
                         const unsigned long long now = wall_clock64();
                         if (t0 == 0) t0 = now;
