@@ -138,6 +138,12 @@ ow_status check_records(const ow_group *g, const ow_cascade_params *params, int 
     return ow::validate_records(params, count, delta);
 }
 
+bool gather_in_flight(const ow_group *g) {
+    for (int i = 0; i < g->shards; ++i)
+        if (g->s[i].pending) return true;
+    return false;
+}
+
 // one shard's part of a gather, on its worker thread
 ow_status gather_begin_shard(ow_group *g, int i) {
     Shard &sh = g->s[i];
@@ -395,6 +401,7 @@ ow_status ow_group_get_maps(ow_group *g, int32_t cascade, void *disp, void *norm
     if (!g) return fail(OW_ERR_INVALID, "null group");
     if (cascade < 0 || cascade >= g->layers) return fail(OW_ERR_INVALID, "cascade %d out of range [0,%d)", cascade, g->layers);
     if (!g->gathered) return fail(OW_ERR_STATE, "the gathered arrays are empty: ow_group_gather_begin / ow_group_gather_wait first");
+    if (gather_in_flight(g)) return fail(OW_ERR_STATE, "a gather is in flight (the arrays are being written): ow_group_gather_wait first");
     int caller_dev = -1;
     (void)hipGetDevice(&caller_dev);
     auto run = [&]() -> ow_status {
@@ -416,6 +423,7 @@ ow_status ow_group_sample_surface(ow_group *g, const float *xz, int32_t count, c
     if (num_cascades < 1 || num_cascades > std::min(g->total, OW_MAX_CASCADES))
         return fail(OW_ERR_INVALID, "num_cascades %d outside [1,%d]", num_cascades, std::min(g->total, OW_MAX_CASCADES));
     if (!g->gathered) return fail(OW_ERR_STATE, "the gathered arrays are empty: ow_group_gather_begin / ow_group_gather_wait first");
+    if (gather_in_flight(g)) return fail(OW_ERR_STATE, "a gather is in flight (the arrays are being written): ow_group_gather_wait first");
     if (count == 0) return OW_OK;
     if (!xz || !map_scales || !out) return fail(OW_ERR_INVALID, "null argument");
     int caller_dev = -1;

@@ -897,6 +897,8 @@ struct ow_imported {
     hipExternalMemory_t ext = nullptr;
     void *ptr = nullptr;
     int device = 0;
+    int fd = -1;  // our duplicate of the caller's descriptor: this runtime neither takes ownership of an imported descriptor nor closes it
+                  // (measured: forty import / release cycles left forty descriptors open), so it is closed by ow_release_buffer
 };
 
 ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t offset, size_t bytes, ow_imported **out, void **device_ptr) {
@@ -937,13 +939,16 @@ ow_status ow_import_buffer(int32_t device_id, int32_t fd, size_t offset, size_t 
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipDestroyExternalMemory(ext);
+        close(own);
         return fail(OW_ERR_HIP, "hipExternalMemoryGetMappedBuffer failed: %s", hipGetErrorString(e));
     }
     ow_imported *im = new (std::nothrow) ow_imported();
     if (!im) {
         (void)hipDestroyExternalMemory(ext);
+        close(own);
         return fail(OW_ERR_NOMEM, "out of host memory");
     }
+    im->fd = own;
     im->ext = ext;
     im->ptr = ptr;
     im->device = dev;
@@ -958,6 +963,7 @@ void ow_release_buffer(ow_imported *im) {
     (void)hipGetDevice(&caller_dev);
     (void)hipSetDevice(im->device);
     (void)hipDestroyExternalMemory(im->ext);
+    if (im->fd >= 0) close(im->fd);
     delete im;
     if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }

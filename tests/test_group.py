@@ -53,6 +53,9 @@ def test_gathered_arrays_hold_the_snapshot_of_every_shard(n, shards, per, force_
     grp.run(UPDATE_DELTA, params, 5)
     grp.gather_begin()                 # snapshot of tick 5 ...
     grp.run(UPDATE_DELTA, params, 4)   # ... while four more ticks overwrite the live maps
+    with pytest.raises(_lib.OceanWavesError) as e:   # the arrays are being written: no reading them before the wait
+        grp.get_maps(0)
+    assert e.value.status == _lib.OW_ERR_STATE
     grp.gather_wait()
     ms, nbytes = grp.gather_stats()
     assert nbytes == per * n * n * 16 and ms > 0.0

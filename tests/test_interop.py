@@ -170,3 +170,56 @@ def test_offset_import_and_refusal_of_packed_caller_memory():
     assert L.ow_export_maps(packed.context, C.byref(d), C.byref(m), C.byref(nb)) == _lib.OW_ERR_STATE and b"whole buffer" in L.ow_last_error()
     assert d.value == -1 and m.value == -1
     packed.free()
+
+
+def test_import_release_cycles_leak_no_descriptors_and_no_memory():
+    """every ow_import_buffer duplicates the caller's descriptor for the runtime; after ow_release_buffer nothing of it may be left"""
+    import torch
+    L = _lib.load()
+    gen, params = make(256, [0, 1])
+    gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    dfd, nfd, nbytes = export(gen)
+    try:
+        def cycle():
+            im, ptr = C.c_void_p(), C.c_void_p()
+            _lib.check(L.ow_import_buffer(0, dfd, 0, nbytes, C.byref(im), C.byref(ptr)))
+            first = read_device(ptr, 64)
+            L.ow_release_buffer(im)
+            return first
+        want = cycle()
+        fds0, free0 = len(os.listdir("/proc/self/fd")), torch.cuda.mem_get_info()[0]
+        for _ in range(40):
+            assert np.array_equal(cycle(), want)
+        assert len(os.listdir("/proc/self/fd")) <= fds0 + 1, (fds0, len(os.listdir("/proc/self/fd")))
+        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
+    finally:
+        os.close(dfd)
+        os.close(nfd)
+
+
+def test_contexts_and_groups_come_and_go_without_leaking_device_memory():
+    import torch
+    from godotoceanwaves_amd import WaveGeneratorGroup
+    def once():
+        gen, params = make(512, [0, 1, 2, 3])
+        gen.run(UPDATE_DELTA, params, 6)           # grows the scratch (tick groups)
+        gen.readback_begin([0, 3])
+        gen.readback_wait(3)
+        gen.free()
+        grp = WaveGeneratorGroup()
+        grp.map_size = 256
+        grp.force_peer_path = True
+        grp.init_gpu([0, 0, 0], 2)
+        p = [WaveCascadeParameters(**cascade_preset(i)) for i in range(6)]
+        grp.run(UPDATE_DELTA, p, 5)
+        grp.gather_begin()
+        grp.gather_wait()
+        grp.free()
+    once()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        once()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (16 << 20), (free0, torch.cuda.mem_get_info()[0])
