@@ -820,10 +820,14 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         f = 1;
     }
     // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
-    const int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
+    int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
     if (depth != 0) {
         OW_HIP(hipSetDevice(c->device));
-        if (ow_status st = ensure_scratch(c, depth > 0 ? 2 * depth * count : 2 * c->pair_slots); st != OW_OK) return st;
+        // the merged launches keep several ticks of intermediate in flight; if that scratch cannot be had the run is not lost: it goes
+        // out one launch per pass (same results)
+        if (ensure_scratch(c, depth > 0 ? 2 * depth * count : 2 * c->pair_slots) != OW_OK) depth = 0;
+    }
+    if (depth != 0) {
         ow_status st = depth > 0 ? run_tick_groups(c, delta, params, count, frames - f, depth) : run_tick_pairs(c, delta, params, count, frames - f);
         if (st != OW_OK) return st;
         f = frames;
