@@ -1,4 +1,4 @@
-"""The C-ABI's contract around the hot path (include/ocean_waves.h, ABI version 2): the parameter records are COPIED by
+"""The C-ABI's contract around the hot path (include/ocean_waves.h, ABI version 2, kept in 3): the parameter records are COPIED by
 ow_update (wave_generator.gd:108 keeps an Array reference; a C / C# caller's memory is only borrowed during the call), bad
 records are refused on the way in (before anything of the caller's is changed, armed or launched), the exported setters'
 clamps (wave_cascade_parameters.gd:15,20) hold for a caller that has no setters, and a device-side wait that gives up is
