@@ -428,3 +428,28 @@ def test_long_run_matches_the_oracle_at_the_final_time():
                 # time - delta + delta is not bit for bit the accumulated time: allow the phase of one FP64 ulp at 520 s (nothing)
                 # plus the usual tolerance
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name, H.relmax(f32[..., c], ref[..., c]))
+
+
+@pytest.mark.parametrize("n,ci,t0", [(1024, 2, 86400.0), (256, 7, 14400.0), (1024, 0, 3600.0)])
+def test_parity_holds_at_the_phases_of_a_long_session(n, ci, t0):
+    """omega * t reaches 1e5 .. 1e6 rad after hours of simulated time -- beyond the range the three-step Cody-Waite reduction of
+    sincos_phase is exact for (ow_device.h).  What matters is the result: the energy sits at low omega, and the FP32 channels stay
+    within 1e-5 of the oracle (glibc sinf / cosf of the same FP32 phase) after a simulated day (profiles/r03_long_time_parity.txt).
+    (The reference itself degrades earlier: `time` is an FP32 push constant, 8 ms per ulp at 86 400 s.)"""
+    gen = WaveGenerator()
+    gen.map_size = n
+    gen.debug_f32 = True
+    gen.init_gpu(2)
+    params = [WaveCascadeParameters(**cascade_preset(ci))]
+    params[0].time = t0
+    og = H.oracle_generator(n, [ci])
+    og.params[0].time = t0
+    for _ in range(2):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    f32, ref = gen.get_maps_f32(0), og.f32(0)
+    for c, name in enumerate(H.CHANNELS):
+        if name != "foam":
+            assert H.relmax(f32[..., c], ref[..., c]) < 2e-5, name
+    assert H.fp16_close(gen.get_maps(0)[0], og.displacement(0)) <= 1.0
