@@ -20,7 +20,8 @@
            ow_process callers get, no look-ahead across ticks), `roofline.residency` says what of the working set fits the
            256 MiB Infinity Cache (so a reader knows when "HBM GB/s" is partly cache traffic).
   sweep  : --sweep appends one line per BASELINE configuration (256^2 x 4, 1024^2 x {1,4,8}, 2048^2 x 4), each with its
-           own roofline and CPU baseline, to --sweep-out (profiles/) and prints the headline line last.
+           own roofline and CPU baseline, to --sweep-out (profiles/) and prints the headline line last; --sweep-grid does the same
+           over north_star's whole grid, 256^2 .. 2048^2 x {1, 4, 8} cascades.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -52,6 +53,8 @@ FAMILY_BYTES = {"standard": (44, 52), "layer_parallel": (44, 52), "compact": (32
 SUFFIX = {"standard": "", "layer_parallel": "_lp", "compact": "c", "layer_parallel_compact": "c_lp"}
 MERGED_KERNEL = {"tick_groups_compact": "k_tick_group_c_lp", "tick_pairs_compact": "k_tick_pair_c"}  # ow_run's launches merged across ticks
 SWEEP = [(256, 4), (1024, 1), (1024, 8), (2048, 4), (1024, 4)]  # BASELINE.json configs C2, C3', C4 (per node), C5, C3 (headline last)
+# north_star's whole grid: "synthetic 256^2 - 2048^2 x {1, 4, 8}-cascade configs" (headline last)
+SWEEP_GRID = [(n, c) for n in (256, 512, 1024, 2048) for c in (1, 4, 8) if (n, c) != (1024, 4)] + [(1024, 4)]
 
 
 def parse():
@@ -77,6 +80,7 @@ def parse():
     ap.add_argument("--no-unmerged", action="store_true", help="skip the second timed region (one launch per pass) behind roofline.unmerged")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample size in seconds of host work")
     ap.add_argument("--sweep", action="store_true", help="one line per BASELINE configuration, appended to --sweep-out")
+    ap.add_argument("--sweep-grid", action="store_true", help="like --sweep, over the whole grid 256^2 .. 2048^2 x {1, 4, 8} cascades")
     ap.add_argument("--sweep-out", default=os.path.join(ROOT, "profiles", "sweep.jsonl"))
     return ap.parse_args()
 
@@ -456,7 +460,9 @@ def main():
 
     if args.cascades is None:
         args.cascades = 4 if world == 1 else 1  # the headline config (C3) on one GPU; BASELINE config C4's shape (one cascade per GPU) on a node
-    configs = SWEEP if args.sweep else [(args.map_size, args.cascades)]
+    if args.sweep_grid:
+        args.sweep = True
+    configs = SWEEP_GRID if args.sweep_grid else (SWEEP if args.sweep else [(args.map_size, args.cascades)])
     for n, C in configs:
         out = measure(args, torch, dist, world, rank, local_rank, n, C)
         if rank == 0:
