@@ -2,7 +2,6 @@
 single-process host.  CPU: builds and fails loudly without a device.  GPU (one MI355X: two / four shards on device 0, every shard
 through the peer path): its checksum of the gathered arrays equals the Python mirror's on the same schedule, whatever the device
 list (cascades are independent units)."""
-import hashlib
 import os
 import subprocess
 
