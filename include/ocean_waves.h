@@ -28,7 +28,7 @@ extern "C" {
 #define OW_ABI_VERSION 3 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word;
                             3: ow_group_* (cascades sharded over several devices, gather into the consumer's arrays), records are
                                validated on the way in (ow_update / ow_set_cascade_params), sticky device-side failures,
-                               ow_export/import_maps (dma-buf hand-off) */
+                               ow_export_maps / ow_import_buffer (dma-buf hand-off) */
 
 typedef enum ow_status {
     OW_OK = 0,
