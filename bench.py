@@ -421,7 +421,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     if gat is not None:
         out["final_gather_ms"] = round(gather_ms, 3)
         out["gather_bytes"] = {"sent_per_rank": gat.bytes_sent, "received_rank0": gat.bytes_received}
-        out["gather"] = {"mode": args.gather, "every_ticks": gather_every, "overlap": not args.no_overlap, **(cadence or {}),
+        out["gather"] = {"mode": gat.mode, **({"fallback": gat.fallback} if gat.fallback else {}), "every_ticks": gather_every, "overlap": not args.no_overlap, **(cadence or {}),
                          "bound": ("links: --steps is shorter than the cadence the links sustain, the region holds one gather and lasts max(compute, gather)"
                                    if (cadence and cadence["uncapped_every_ticks"] > args.steps) else "compute: every gather hides under its chunk of ticks"),
                          # what the links deliver: bytes into the consumer per gather / the time between gathers in the timed region

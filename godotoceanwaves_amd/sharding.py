@@ -50,6 +50,7 @@ class MapGatherer:
         if mode == "all" or rank == root:
             self.out = torch.empty((world,) + shape, dtype=disp.dtype, device=disp.device)
         self.work = None
+        self.fallback = None  # set when the backend refused gather-to-root and the exchange fell back to an all-gather
         self.bytes_sent = self.snap.numel() * self.snap.element_size()
         self.bytes_received = (self.out.numel() * self.out.element_size()) if self.out is not None else 0
 
@@ -86,7 +87,18 @@ class MapGatherer:
             # flat views: the concatenating form of all_gather_into_tensor, accepted by both RCCL and gloo
             return dist.all_gather_into_tensor(self.out.view(u8).view(-1), self.snap.view(u8).view(-1), async_op=async_op)
         parts = [self.out[r].view(u8) for r in range(self.world)] if self.rank == self.root else None
-        return dist.gather(self.snap.view(u8), gather_list=parts, dst=self.root, async_op=async_op)
+        try:
+            return dist.gather(self.snap.view(u8), gather_list=parts, dst=self.root, async_op=async_op)
+        except (RuntimeError, NotImplementedError) as e:
+            # A backend without gather (every rank sees the refusal at the same call, before anything was sent): the exchange
+            # degrades to the all-gather for the rest of the run -- N times the receive volume, said so in `fallback` -- rather
+            # than costing the run.
+            self.fallback = f"gather-to-root refused by the backend ({type(e).__name__}: {str(e)[:120]}): all_gather instead"
+            self.mode = "all"
+            if self.out is None:
+                self.out = self.torch.empty((self.world,) + tuple(self.snap.shape), dtype=self.snap.dtype, device=self.snap.device)
+            self.bytes_received = self.out.numel() * self.out.element_size()
+            return dist.all_gather_into_tensor(self.out.view(u8).view(-1), self.snap.view(u8).view(-1), async_op=async_op)
 
     def wait(self):
         """host-level: returns when the most recent gather's bytes are in `out`"""

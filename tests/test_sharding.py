@@ -43,6 +43,13 @@ def _worker(rank, world, port, n, per_rank, frames, mode, out_dir):
     layers = max(2, per_rank)  # the array textures have max(2, C) layers (water.gd:91); only the owned ones may travel
     disp = torch.full((layers, n, n, 4), 0x7E00, dtype=torch.int16)  # NaN bits in the spare layer: must never show up
     norm = torch.full((layers, n, n, 4), 0x7E00, dtype=torch.int16)
+    refuse = mode == "root_refused"   # a backend without gather-to-root: the exchange must degrade to the all-gather, not fail
+    if refuse:
+        mode = "root"
+
+        def no_gather(*a, **k):
+            raise RuntimeError("gather is not supported by this backend (test stand-in)")
+        dist.gather = no_gather
     gat = sharding.MapGatherer(torch, dist, world, rank, disp, norm, per_rank, mode=mode, root=0)
     assert gat.bytes_sent == 2 * per_rank * n * n * 8
     assert gat.bytes_received == (world * gat.bytes_sent if (mode == "all" or rank == 0) else 0)
@@ -58,12 +65,14 @@ def _worker(rank, world, port, n, per_rank, frames, mode, out_dir):
         d, m = gat.maps()
         np.save(os.path.join(out_dir, "disp.npy"), d.numpy())
         np.save(os.path.join(out_dir, "norm.npy"), m.numpy())
-    elif mode == "root":
+    elif mode == "root" and not refuse:
         assert gat.maps() is None
+    if refuse:
+        assert gat.mode == "all" and "all_gather instead" in gat.fallback and gat.bytes_received == world * gat.bytes_sent
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("per_rank,mode", [(2, "all"), (1, "all"), (2, "root"), (1, "root")])
+@pytest.mark.parametrize("per_rank,mode", [(2, "all"), (1, "all"), (2, "root"), (1, "root"), (1, "root_refused")])
 def test_two_rank_gloo_shard_and_gather(tmp_path, per_rank, mode):
     """per_rank = 1 is BASELINE config C4's shape (one cascade per GPU): the spare second array layer must not travel"""
     import torch.multiprocessing as mp
