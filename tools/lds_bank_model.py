@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Bank-conflict model of the row transforms' LDS traffic (developer tool; nothing here runs on a GPU).
 
-LDS: 64 banks x 4 B.  A wave's ds_read_b64 / ds_write_b64 is served in two halves of 32 lanes, every lane taking a pair of adjacent
-banks; a half needs as many passes as its busiest bank has distinct addresses (equal addresses broadcast).  For every map size the
-script walks the exchange accesses of one row transform (ow_device.h fft_stage_write / fft_stage_read, several rows per wave where a
-row is shorter than a wave) under the padding functions e + (e >> 4) (rounds 1-2) and e + (e >> 5), and prints passes / ideal.
-Round 2's PMC counters put 14 % of the tick-pair kernel's LDS-active cycles in bank conflicts; the model gives +14.5 % for the 1024
-plan under e + (e >> 4) (the stage-1 reads take two passes per half) and 0 under e + (e >> 5)."""
+Rules (/opt/skills/guides/MI355X_MICROARCH.md, LDS): 64 banks of 4 B.  ds_read_b64: two groups of 32 lanes, bank = (a / 4) mod 64;
+ds_write_b64: four groups of 16 CONTIGUOUS lanes, bank = (a / 4) mod 32.  A group needs as many passes as its busiest bank has distinct
+addresses (equal addresses broadcast).  For every map size the script walks the exchange accesses of one row transform (ow_device.h
+fft_stage_write / fft_stage_read; several rows per wave where a row is shorter than a wave) under three slot maps and prints the extra
+passes.  Checked against the counters: map 0 gives +32 passes per 1024-point transform = the 14 % of LDS-active cycles round 2 measured as
+SQ_LDS_BANK_CONFLICT; map 1 gives +64 = the doubling round 3 measured (profiles/r03_pmc_lds_counters.txt); map 2 gives 0."""
 
 
 def plan(N):
@@ -20,12 +20,23 @@ def region(N):
     return N + N // 16 + 4  # plan_region_cplx
 
 
-def passes(addrs):
+def read_passes(addrs):  # addresses in 8-byte units, one per lane
     total = 0
     for h in range(2):
         banks = {}
         for a in set(addrs[32 * h:32 * h + 32]):
             for b in ((2 * a) % 64, (2 * a + 1) % 64):
+                banks[b] = banks.get(b, 0) + 1
+        total += max(banks.values())
+    return total
+
+
+def write_passes(addrs):
+    total = 0
+    for g in range(4):
+        banks = {}
+        for a in set(addrs[16 * g:16 * g + 16]):
+            for b in ((2 * a) % 32, (2 * a + 1) % 32):
                 banks[b] = banks.get(b, 0) + 1
         total += max(banks.values())
     return total
@@ -41,34 +52,28 @@ def transform(N, slot, lane_exchange=True):
             continue  # the last exchange runs on the row-swap instructions, not through LDS
         Rj, sj, Rn, sn = R[J], s[J], R[J + 1], s[J + 1]
         B, Bn, mn = (N // Rj) // T, (N // Rn) // T, (N // sn) // Rn
-        w = sum(passes([r * region(N) + slot(((t + T * b) % sj) + sj * (Rj * ((t + T * b) // sj) + k)) for r, t in rows(wv)])
+        w = sum(write_passes([r * region(N) + slot(((t + T * b) % sj) + sj * (Rj * ((t + T * b) // sj) + k)) for r, t in rows(wv)])
                 for wv in waves for b in range(B) for k in range(Rj))
-        r_ = sum(passes([r * region(N) + slot(((t + T * b) % sn) + sn * (((t + T * b) // sn) + mn * i)) for r, t in rows(wv)])
+        r_ = sum(read_passes([r * region(N) + slot(((t + T * b) % sn) + sn * (((t + T * b) // sn) + mn * i)) for r, t in rows(wv)])
                  for wv in waves for b in range(Bn) for i in range(Rn))
-        out[f"stage {J} write"] = (w, 2 * len(waves) * B * Rj)
+        out[f"stage {J} write"] = (w, 4 * len(waves) * B * Rj)
         out[f"stage {J + 1} read"] = (r_, 2 * len(waves) * Bn * Rn)
     return out
 
 
-def staging_1024():
-    """the other LDS accesses of the 1024^2 pass 1 (twiddle table reads, staged rows for the transposed store): all conflict-free"""
-    N, T = 1024, 64
-    ops = []
-    for (R, s, m) in ((16, 1, 64), (16, 16, 4)):
-        ops += [[(k - 1) * m + t // s for t in range(64)] for k in range(1, R)]
-    ops += [[t + T * o for t in range(64)] for o in range(16)]
-    ops += [[(tau % 8) * region(N) + tau // 8 + T * k for tau in range(64)] for k in range(16)]
-    return sum(passes(o) for o in ops), 2 * len(ops)
+def swap34(e):
+    return (e & ~0x18) | (((e >> 3) & 1) << 4) | (((e >> 4) & 1) << 3)
 
+
+MAPS = (("0: e + (e >> 4)          [rounds 1-2]", lambda e: e + (e >> 4)),
+        ("1: e + (e >> 5)          [round 3, first try]", lambda e: e + (e >> 5)),
+        ("2: swap34(e) + (e >> 5)  [shipped]", lambda e: swap34(e) + (e >> 5)))
 
 if __name__ == "__main__":
     for N in (128, 256, 512, 1024, 2048):
-        for name, f in (("e + (e >> 4)", lambda e: e + (e >> 4)), ("e + (e >> 5)", lambda e: e + (e >> 5))):
+        for name, f in MAPS:
+            vals = [f(e) for e in range(N)]
+            assert len(set(vals)) == N and max(vals) < region(N), (N, name)
             r = transform(N, f)
             tot, ideal = sum(v[0] for v in r.values()), sum(v[1] for v in r.values())
-            print(f"N = {N:4d}  {name}:  {tot:4d} passes / {ideal:4d} ideal   " + "  ".join(f"{k} {v[0]}/{v[1]}" for k, v in r.items()))
-    st, st_ideal = staging_1024()
-    for name, f in (("e + (e >> 4)", lambda e: e + (e >> 4)), ("e + (e >> 5)", lambda e: e + (e >> 5))):
-        r = transform(1024, f)
-        tot, ideal = sum(v[0] for v in r.values()) + st, sum(v[1] for v in r.values()) + st_ideal
-        print(f"1024^2 pass 1, all LDS accesses of one row transform + staging, {name}: {tot} / {ideal} = +{100 * (tot - ideal) / ideal:.1f} %")
+            print(f"N = {N:4d}  map {name:46s} +{tot - ideal:3d} passes over {ideal:3d}   " + "  ".join(f"{k} {v[0]}/{v[1]}" for k, v in r.items()))
