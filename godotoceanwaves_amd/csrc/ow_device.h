@@ -88,26 +88,31 @@ constexpr int plan_region_cplx(int N) { return N + N / 16 + 4; }
 constexpr int plan_tw_size(int N, int j) { return (plan_R(N, j) - 1) * plan_m(N, j); }
 constexpr int plan_tw_off(int N, int j) { return j == 0 ? 0 : (j == 1 ? plan_tw_size(N, 0) : plan_tw_size(N, 0) + plan_tw_size(N, 1)); }
 constexpr int plan_tw_total(int N) { return plan_tw_off(N, plan_S(N) - 1); }
-// LDS slot of element e of a row's exchange image: bits 3 and 4 of e swapped, plus e >> 5.  The rules it is built for
-// (MI355X_MICROARCH.md, LDS): a wave's ds_read_b64 is served in two groups of 32 lanes over 64 banks -- conflict-free when the 32 slots
-// (8-byte units) of a group are distinct mod 32 --, a ds_write_b64 in four groups of 16 CONTIGUOUS lanes over 32 banks -- distinct mod 16.
-//   stage-0 writes: element 16 t + k over 16 consecutive lanes t -> bit 4 of the element (t's lowest bit) lands on slot bit 3, the next three
-//     bits of t arrive through e >> 5 on slot bits 0-2: (t & 1) * 8 + ((t >> 1) & 7) + const, a permutation of 0..15;
-//   stage-1 reads: element q + 16 p + 64 i over lanes (q = 0..15, p = 0..1 per group) -> q's bits 0-2 stay, its bit 3 lands on slot bit 4,
-//     p's low bit on slot bit 3: a permutation of 0..31.
-// History, because the counters tell it: rounds 1-2 used e + (e >> 4) -- writes conflict-free, but the two 16-lane runs of every stage-1
-// read overlap in one slot: +32 LDS passes per 1024-point transform, the 14 % of LDS-active cycles that
-// profiles/r02_pmc_sq_tick_pairs_1024x4.txt counts as bank conflicts.  Round 3 first tried e + (e >> 5), derived from a model that gave
-// writes the reads' grouping: it freed the reads and made every stage-0 write two-way conflicted -- SQ_LDS_BANK_CONFLICT DOUBLED
-// (profiles/r03_pmc_lds_counters.txt).  With the guide's grouping the model (tools/lds_bank_model.py) reproduces both counter readings, and
-// this map comes out of it: 0 extra passes at 512 and 1024, 32 instead of 96 at 128, unchanged at 256 (32) and 2048 (128: with three LDS
-// stages the two writes and the two reads constrain the same bits).  No effect on time either way (the LDS is 35 % busy and not on the
-// critical path: profiles/r03_lds_padding_ab.txt) -- the map is private to a row's exchange, results are bit-identical.
+// LDS slot of element e of a row's exchange image: e + (e >> 4) -- one padding slot per 16 elements.
+// The LDS rules that matter (MI355X_MICROARCH.md, LDS): a wave's ds_write_b64 is served in four groups of 16 CONTIGUOUS lanes over 32 banks
+// -- conflict-free when the 16 slots (8-byte units) of a group are distinct mod 16 --, a ds_read_b64 in two groups of 32 lanes over 64 banks
+// -- distinct mod 32.  Under this map the stage-0 writes (element 16 t + k over lanes t: 17 t + k) are conflict-free and every stage-1 read
+// (element q + 16 p + 64 i over lanes (q, p): the runs q + 17 p of p = 0 and p = 1 share one slot mod 32) takes two passes per group instead
+// of one: +32 passes per 1024-point transform, the 14 % of LDS-active cycles that round 2's SQ counters report as bank conflicts.
+// Round 3 went after them (tools/lds_bank_model.py, profiles/r03_pmc_lds_counters.txt, profiles/r03_lds_padding_ab.txt):
+//   map 1, e + (e >> 5): frees the reads, two-way conflicts on every stage-0 write -- SQ_LDS_BANK_CONFLICT of k_tick_pair_c<1024> 17.05 M ->
+//     34.09 M (it came out of a first model that gave writes the reads' lane groups; the counter corrected the model);
+//   map 2, bits 3 and 4 of e swapped, + (e >> 5) (at 2048, map 1 for the second exchange, whose region is rewritten in between): the model's
+//     answer with the right groups -- SQ_LDS_BANK_CONFLICT = 0 for k_tick_pair_c<1024> AND for k_pass2c<2048> (24.1 M before), LDS-active cycles
+//     -14 % / -19 %.  Results bit-identical (the map is private to a row's exchange).
+// Time did not move for any of them, at any size, on the same box (1024^2 x 4 53.5 vs 53.6 us, 2048^2 x 1 63.3 vs 63.1): the LDS is not on
+// the critical path of these kernels.  And map 2's lane part costs eight integer operations per stage where this one costs three, which
+// pushes k_pass1c_split<2048> and k_tick_group_c_lp<256> from 126 to 128 VGPRs plus 16 - 20 bytes of scratch.  A change that buys nothing
+// and spills is not shipped: the map of rounds 1-2 stays, the others remain selectable for A/B builds.
 #ifndef OW_LDS_SLOT_MAP
-#define OW_LDS_SLOT_MAP 2  // 0: e + (e >> 4) (rounds 1-2), 1: e + (e >> 5), 2: swap bits 3 / 4, + (e >> 5)   (A/B builds: scripts/build_variant.sh)
+#define OW_LDS_SLOT_MAP 0  // 0: e + (e >> 4) (shipped), 1: e + (e >> 5), 2: bits 3 / 4 swapped + (e >> 5), second exchange map 1   (scripts/build_variant.sh mapN -DOW_LDS_SLOT_MAP=N)
 #endif
+// X = which exchange of the transform (0: between stages 0 and 1; 1: between stages 1 and 2, which goes through LDS at 2048 only)
+template <int X>
 constexpr int lds_slot(int e) {
-    return OW_LDS_SLOT_MAP == 0 ? e + (e >> 4) : OW_LDS_SLOT_MAP == 1 ? e + (e >> 5) : ((e & ~0x18) | (((e >> 3) & 1) << 4) | (((e >> 4) & 1) << 3)) + (e >> 5);
+    return OW_LDS_SLOT_MAP == 0 ? e + (e >> 4)
+           : (OW_LDS_SLOT_MAP == 1 || (OW_LDS_SLOT_MAP == 2 && X == 1)) ? e + (e >> 5)
+                                                                        : ((e & ~0x18) | (((e >> 3) & 1) << 4) | (((e >> 4) & 1) << 3)) + (e >> 5);
 }
 // whole workgroup: [twiddle table][8 x row region]
 constexpr int plan_wg_lds_cplx(int N) { return plan_region_cplx(N) * kWgRows + plan_tw_total(N); }
@@ -249,18 +254,18 @@ OW_DEV void fft_stage_compute(cplx *d, int t, const cplx *__restrict__ tw) {
 // LDS slot of the element a lane writes after / reads before a stage.  For every plan used here the slot is
 // affine in (b, k): slot(t, b, k) = slot(t, 0, 0) + [slot(0, b, k) - slot(0, 0, 0)], because T is a multiple of
 // 16 (or, at N = 128, the lane index stays below 16): the lane part and the (b, k) part of the element index occupy disjoint
-// bits, and lds_slot -- a bit permutation plus e >> 5 -- is additive over numbers with disjoint bits.  The lane part is computed once per stage; the (b, k) part is a compile-time DS offset.
+// bits, and every map of lds_slot (a bit permutation plus a shifted copy) is additive over numbers with disjoint bits.  The lane part is computed once per stage; the (b, k) part is a compile-time DS offset.
 template <int N, int J>
 constexpr int wr_slot(int t, int b, int k) {
     const int R = plan_R(N, J), T = plan_T(N), s = plan_s(N, J);
     const int u = t + T * b, q = u % s, p = u / s;
-    return lds_slot(q + s * (R * p + k));
+    return lds_slot<J>(q + s * (R * p + k));
 }
 template <int N, int J>
 constexpr int rd_slot(int t, int b, int i) {
     const int T = plan_T(N), s = plan_s(N, J), m = plan_m(N, J);
     const int u = t + T * b, q = u % s, p = u / s;
-    return lds_slot(q + s * (p + m * i));
+    return lds_slot<J - 1>(q + s * (p + m * i));
 }
 
 template <int N, int J>

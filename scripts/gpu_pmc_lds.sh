@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=${R:-r03}; O=gpurun_out/${R}_pmc_lds; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 V=$GRAFT_REPO_ROOT/godotoceanwaves_amd/csrc/build/variants
-for lib in default map0 map1; do
+for lib in ${LIBS:-default map0 map1}; do
   for cfg in "1024 4" "2048 1"; do
     set -- $cfg
     if [ $lib = default ]; then unset OCEAN_WAVES_LIB; else export OCEAN_WAVES_LIB=$V/$lib.so; [ -f $OCEAN_WAVES_LIB ] || continue; fi
