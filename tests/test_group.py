@@ -202,3 +202,47 @@ def test_group_argument_errors_and_bad_records():
         grp.update_all(UPDATE_DELTA, params)
     assert e.value.status == _lib.OW_ERR_INVALID and "cascade 1" in str(e.value) and [p.time for p in params] == t0
     grp.free()
+
+
+def test_resharding_through_the_checkpoint_state():
+    """SURVEY.md section 5 (checkpoint / resume): the persistent state of a cascade is its `time`, its parameters + seed (the spectrum is
+    regenerated from them) and the FP16 foam channel.  A run on 2 shards x 2 cascades is stopped, its state carried over -- the gathered
+    normal maps through ow_set_normal_map, the parameter objects as they are with their dirty flags raised -- into 4 shards x 1 cascade,
+    and continued: bit for bit the maps of the run that was never interrupted."""
+    n, ids = 256, [0, 1, 2, 3]
+
+    def group(shards, per):
+        g = WaveGeneratorGroup()
+        g.map_size = n
+        g.force_peer_path = True
+        g.init_gpu([0] * shards, per)
+        return g
+
+    def gathered(g):
+        g.gather_begin()
+        g.gather_wait()
+        return [g.get_maps(c) for c in ids]
+
+    ref = group(2, 2)
+    pr = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    ref.run(UPDATE_DELTA, pr, 6)
+    ref.run(UPDATE_DELTA, pr, 5)
+    want = gathered(ref)
+    ref.free()
+
+    a = group(2, 2)
+    pa = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    a.run(UPDATE_DELTA, pa, 6)
+    state = gathered(a)          # the checkpoint: maps (foam in normal.a) + the parameter objects (time inside)
+    a.free()
+
+    b = group(4, 1)              # another partition of the same cascades
+    for c in ids:
+        b.shard(c).set_normal_map(0, state[c][1])
+        pa[c].should_generate_spectrum = True    # the new owner has no spectrum yet: regenerated from parameters + seed
+    b.run(UPDATE_DELTA, pa, 5)
+    got = gathered(b)
+    for c in ids:
+        assert np.array_equal(bits(got[c][0]), bits(want[c][0])) and np.array_equal(bits(got[c][1]), bits(want[c][1])), c
+    assert [p.time for p in pa] == [p.time for p in pr]
+    b.free()
