@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
         par[i].spectrum_seed[0] = 1000 + 17 * i; par[i].spectrum_seed[1] = -2000 + 31 * i;
         par[i].time = 120.0 + 3.14159265358979323846 * i;
         map_scales[i][0] = map_scales[i][1] = 1.0f / tile[i];   /* water.gd:105-109 */
-        map_scales[i][2] = par[i].displacement_scale; map_scales[i][3] = par[i].normal_scale;
+        map_scales[i][2] = (float)par[i].displacement_scale; map_scales[i][3] = (float)par[i].normal_scale;
     }
 
     uint64_t sum = 0;

@@ -71,7 +71,7 @@ public:
         std::vector<std::array<float, 4>> s(parameters_.size());
         for (size_t i = 0; i < parameters_.size(); ++i) {
             const auto tile = parameters_[i]->tile_length();
-            s[i] = {1.0f / tile.first, 1.0f / tile.second, parameters_[i]->displacement_scale(), parameters_[i]->normal_scale()};
+            s[i] = {1.0f / tile.first, 1.0f / tile.second, (float)parameters_[i]->displacement_scale(), (float)parameters_[i]->normal_scale()};  // Vector4: FP32
         }
         return s;
     }

@@ -74,7 +74,7 @@ int main(int argc, char **argv) try {
             water.set_updates_per_second(r);
         } else if (cmd == "wind" || cmd == "foam") {
             int i;
-            float v;
+            double v;  // (a GDScript float is FP64: the edit reaches the library un-narrowed)
             ls >> i >> v;
             if (cmd == "wind") water.parameters().at(i)->set_wind_speed(v);  // a live edit: the setter raises the dirty flag
             else water.parameters().at(i)->set_foam_amount(v);

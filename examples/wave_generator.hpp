@@ -33,19 +33,20 @@ inline void check(ow_status st) {
 
 // wave_cascade_parameters.gd:7-42.  The exported properties are private fields behind setters that raise
 // should_generate_spectrum, as the GDScript `set(value)` blocks do; wind_speed / fetch_length clamp at 1e-4 (:15,:20).
+// GDScript floats are FP64 and so are these (ow_cascade_params, ABI 4): the library narrows where the reference does.
 class WaveCascadeParameters {
 public:
     WaveCascadeParameters() { ow_cascade_params_default(&c_); }
 
 #define OW_EXPORT(name, expr)                  \
-    float name() const { return c_.name; }     \
-    void set_##name(float value) {             \
+    double name() const { return c_.name; }    \
+    void set_##name(double value) {            \
         c_.name = (expr);                      \
         c_.should_generate_spectrum = 1;       \
     }
-    OW_EXPORT(wind_speed, value < 1e-4f ? 1e-4f : value)       // :15
+    OW_EXPORT(wind_speed, value < 1e-4 ? 1e-4 : value)       // :15
     OW_EXPORT(wind_direction, value)                           // :17
-    OW_EXPORT(fetch_length, value < 1e-4f ? 1e-4f : value)     // :20
+    OW_EXPORT(fetch_length, value < 1e-4 ? 1e-4 : value)     // :20
     OW_EXPORT(swell, value)                                    // :22
     OW_EXPORT(spread, value)                                   // :25
     OW_EXPORT(detail, value)                                   // :28
@@ -59,10 +60,10 @@ public:
         c_.should_generate_spectrum = 1;
     }
     // consumer-side only: no dirty flag (:9-12)
-    float displacement_scale() const { return c_.displacement_scale; }
-    void set_displacement_scale(float v) { c_.displacement_scale = v; }
-    float normal_scale() const { return c_.normal_scale; }
-    void set_normal_scale(float v) { c_.normal_scale = v; }
+    double displacement_scale() const { return c_.displacement_scale; }
+    void set_displacement_scale(double v) { c_.displacement_scale = v; }
+    double normal_scale() const { return c_.normal_scale; }
+    void set_normal_scale(double v) { c_.normal_scale = v; }
 
     // plain vars of the resource (:37-42)
     std::pair<int32_t, int32_t> spectrum_seed() const { return {c_.spectrum_seed[0], c_.spectrum_seed[1]}; }

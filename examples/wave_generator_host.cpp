@@ -40,8 +40,8 @@ int main(int argc, char **argv) try {
         p->set_time(120.0 + 3.14159265358979323846 * i);
         parameters.push_back(p);
         map_scales[i][0] = map_scales[i][1] = 1.0f / tile[i];  // water.gd:105-109
-        map_scales[i][2] = p->displacement_scale();
-        map_scales[i][3] = p->normal_scale();
+        map_scales[i][2] = (float)p->displacement_scale();
+        map_scales[i][3] = (float)p->normal_scale();
     }
 
     WaveGenerator wave_generator;

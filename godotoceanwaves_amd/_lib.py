@@ -24,11 +24,12 @@ class OceanWavesError(RuntimeError):
 
 
 class ow_cascade_params(C.Structure):
-    """struct ow_cascade_params (WaveCascadeParameters, wave_cascade_parameters.gd:7-42)"""
-    _fields_ = [("tile_length", C.c_float * 2), ("displacement_scale", C.c_float), ("normal_scale", C.c_float),
-                ("wind_speed", C.c_float), ("wind_direction", C.c_float), ("fetch_length", C.c_float),
-                ("swell", C.c_float), ("spread", C.c_float), ("detail", C.c_float), ("whitecap", C.c_float),
-                ("foam_amount", C.c_float), ("spectrum_seed", C.c_int32 * 2),
+    """struct ow_cascade_params (WaveCascadeParameters, wave_cascade_parameters.gd:7-42), ABI 4: the scalar parameters are FP64 as a
+    GDScript caller holds them (the library narrows where the reference does); tile_length is a Vector2 (FP32 components)"""
+    _fields_ = [("tile_length", C.c_float * 2), ("displacement_scale", C.c_double), ("normal_scale", C.c_double),
+                ("wind_speed", C.c_double), ("wind_direction", C.c_double), ("fetch_length", C.c_double),
+                ("swell", C.c_double), ("spread", C.c_double), ("detail", C.c_double), ("whitecap", C.c_double),
+                ("foam_amount", C.c_double), ("spectrum_seed", C.c_int32 * 2),
                 ("should_generate_spectrum", C.c_int32), ("reserved", C.c_int32), ("time", C.c_double),
                 ("foam_grow_rate", C.c_double), ("foam_decay_rate", C.c_double)]
 

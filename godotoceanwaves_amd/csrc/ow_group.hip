@@ -103,6 +103,11 @@ struct ow_group {
     bool own_gdisp = false, own_gnorm = false;
     hipStream_t root_stream = nullptr;  // ow_group_get_maps / ow_group_sample_surface
     bool gathered = false;              // at least one gather has completed
+    // shards (bit i) whose layers of the gathered arrays are NOT maps: the shard's kernels had reported a device-side failure when its
+    // copy landed.  Set by gather_wait_all, lifted by the next gather of that shard that lands cleanly; while a bit is set,
+    // ow_group_get_maps of that shard's layers and ow_group_sample_surface over them are refused (the context-level contract of
+    // ow_sync, carried over to the group's readers).
+    uint32_t faulted_shards = 0;
     float last_copy_ms = 0.0f;
     float *query_xz = nullptr;
     ow::SurfaceSample *query_out = nullptr;
@@ -172,30 +177,51 @@ ow_status gather_begin_shard(ow_group *g, int i) {
     return OW_OK;
 }
 
+// Every pending shard is waited for and polled, whatever happens to the others (a failure of shard 2 must not leave shards 3.. pending
+// for ever); the FIRST failure is what the call returns.
 ow_status gather_wait_all(ow_group *g) {
     float worst = 0.0f;
     bool any = false;
+    ow_status first = OW_OK;
+    std::string first_message;
+    auto note = [&](int i, ow_status st) {
+        g->faulted_shards |= 1u << i;
+        if (first != OW_OK) return;
+        first = st;
+        first_message = "shard " + std::to_string(i) + " (device " + std::to_string(g->s[i].device) + "): " + ow_last_error();
+    };
     for (int i = 0; i < g->shards; ++i) {
         Shard &sh = g->s[i];
         if (!sh.pending) continue;
-        OW_HIP(hipSetDevice(sh.device));
-        OW_HIP(hipEventSynchronize(sh.copy_done));
         sh.pending = false;
+        hipError_t e = hipSetDevice(sh.device);
+        if (e == hipSuccess) e = hipEventSynchronize(sh.copy_done);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            note(i, fail(OW_ERR_HIP, "waiting for the gather's copy failed: %s", hipGetErrorString(e)));
+            continue;
+        }
         any = true;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, sh.copy_start, sh.copy_done) == hipSuccess) worst = std::max(worst, ms);
         else (void)hipGetLastError();
+        // what has landed is only maps if the shard's kernels reported no failure (the copy was ordered behind them)
+        if (ow_status st = ow::poll_status(sh.ctx); st != OW_OK) note(i, st);
+        else g->faulted_shards &= ~(1u << i);  // this shard's layers are maps again
     }
     if (any) {
         g->last_copy_ms = worst;
         g->gathered = true;
     }
-    // what has landed is only maps if no shard's kernels reported a failure (the copies were ordered behind them)
-    for (int i = 0; i < g->shards; ++i)
-        if (ow_status st = ow::poll_status(g->s[i].ctx); st != OW_OK) {
-            ow::set_last_error(("shard " + std::to_string(i) + " (device " + std::to_string(g->s[i].device) + "): " + ow_last_error()).c_str());
-            return st;
-        }
+    if (first != OW_OK) ow::set_last_error(first_message.c_str());
+    return first;
+}
+// the readers' side of it: layers [first, first + count) of the gathered arrays
+ow_status refuse_faulted_layers(const ow_group *g, int first, int count) {
+    for (int layer = first; layer < first + count && layer < g->total; ++layer)
+        if ((g->faulted_shards >> (layer / g->per)) & 1u)
+            return fail(OW_ERR_HIP, "gathered layer %d belongs to shard %d, whose kernels had reported a device-side failure when its layers were "
+                                    "gathered: the bytes are not maps until a later gather of that shard has landed cleanly", layer, layer / g->per);
     return OW_OK;
 }
 
@@ -402,6 +428,7 @@ ow_status ow_group_get_maps(ow_group *g, int32_t cascade, void *disp, void *norm
     if (cascade < 0 || cascade >= g->layers) return fail(OW_ERR_INVALID, "cascade %d out of range [0,%d)", cascade, g->layers);
     if (!g->gathered) return fail(OW_ERR_STATE, "the gathered arrays are empty: ow_group_gather_begin / ow_group_gather_wait first");
     if (gather_in_flight(g)) return fail(OW_ERR_STATE, "a gather is in flight (the arrays are being written): ow_group_gather_wait first");
+    if (ow_status st = refuse_faulted_layers(g, cascade, 1); st != OW_OK) return st;
     int caller_dev = -1;
     (void)hipGetDevice(&caller_dev);
     auto run = [&]() -> ow_status {
@@ -424,6 +451,7 @@ ow_status ow_group_sample_surface(ow_group *g, const float *xz, int32_t count, c
         return fail(OW_ERR_INVALID, "num_cascades %d outside [1,%d]", num_cascades, std::min(g->total, OW_MAX_CASCADES));
     if (!g->gathered) return fail(OW_ERR_STATE, "the gathered arrays are empty: ow_group_gather_begin / ow_group_gather_wait first");
     if (gather_in_flight(g)) return fail(OW_ERR_STATE, "a gather is in flight (the arrays are being written): ow_group_gather_wait first");
+    if (ow_status st = refuse_faulted_layers(g, 0, num_cascades); st != OW_OK) return st;
     if (count == 0) return OW_OK;
     if (!xz || !map_scales || !out) return fail(OW_ERR_INVALID, "null argument");
     int caller_dev = -1;

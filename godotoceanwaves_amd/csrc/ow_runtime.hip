@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -67,8 +68,12 @@ struct ow_context {
     // The status word is consumed by the first synchronising call that sees it; the failure itself is sticky: until the next batch
     // is enqueued every call that hands out map bytes (ow_get_maps, ow_get_maps_f32, ow_sample_surface) keeps failing, and so does
     // the ow_readback_wait of every layer whose copy was in flight when the word was consumed (readback_faulted).
-    bool maps_faulted = false;
+    // Both are bit masks over the array layers: a synchronising call that finds the word set marks the layers recomputed by the batches
+    // enqueued since the previous synchronisation (enqueued_since_sync); a layer's mark is lifted only by a later batch that recomputes
+    // THAT layer (the reference's schedule enqueues one cascade per call: the other layers keep the faulted batch's bytes).
+    uint32_t maps_faulted = 0, enqueued_since_sync = 0;
     uint32_t readback_faulted = 0;
+    size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
     int group_p1_form = -1, group_p2_form = -1;
@@ -137,9 +142,7 @@ constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
 constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
-    size_t pair_texels = kPairTexels;
-    if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS")) pair_texels = (size_t)atol(e) << 20;  // measurement knob: batch size of the tick pairs, in Mi texels
-    const size_t pl = (size_t)c->n * c->n;
+    const size_t pair_texels = c->pair_texels, pl = (size_t)c->n * c->n;
     if (count < 1 || !ow::tick_groups_supported(c->n)) return 0;
     // Where two full-size batches of intermediate next to the spectra do not fit the Infinity Cache (1024^2 x 8: 96 + 2 x 80 MiB), batches
     // of half the size do (96 + 2 x 40): every launch is then one full round of blocks (256 of each pass at 1024^2) instead of two --
@@ -170,6 +173,11 @@ int tick_group_depth_for(const ow_context *c, int count) {
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
+    // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
+    // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
+    c->pair_texels = kPairTexels;
+    if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
+        if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
     if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
     for (int count = 1; count <= c->cascades; ++count) {
         int sizes[OW_MAX_CASCADES];
@@ -269,21 +277,33 @@ ow_status next_events(ow_context *c, hipEvent_t **out, bool single = false) {
 
 // hipStreamSynchronize + the device status word.  hands_out_maps: the caller is about to give map bytes to its caller (everything
 // but a bare ow_sync), which stays refused after a consumed failure until the maps have been recomputed.
-ow_status sync_stream(ow_context *c, bool hands_out_maps = true) {
-    OW_HIP(hipStreamSynchronize(c->stream));
-    if (c->status_host && *c->status_host != 0u) {
-        const uint32_t bits = *c->status_host;
-        *c->status_host = 0u;  // the word is consumed; later batches start clean ...
-        c->maps_faulted = true;  // ... but what the faulted batches left behind stays marked until the maps are recomputed
-        for (int i = 0; i < OW_MAX_CASCADES; ++i)
-            if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
-        return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
-                                "the last synchronisation are invalid", bits, (bits & ow::kStatusRowSyncTimeout) ? ": wave-pair rendezvous timed out" : "");
+// the status word, consumed: marks what the faulted batches left behind (shared by sync_stream and ow::poll_status)
+ow_status consume_status(ow_context *c) {
+    if (!c->status_host || *c->status_host == 0u) {
+        return OW_OK;
     }
-    if (c->maps_faulted && hands_out_maps)
-        return fail(OW_ERR_HIP, "the maps are those of a batch that reported a device-side failure (already returned by an earlier call); "
-                                "they stay invalid until the next batch has been enqueued");
+    const uint32_t bits = *c->status_host;
+    *c->status_host = 0u;                          // the word is consumed; later batches start clean ...
+    c->maps_faulted |= c->enqueued_since_sync;     // ... but what the faulted batches left behind stays marked until those layers are recomputed
+    c->enqueued_since_sync = 0;
+    for (int i = 0; i < OW_MAX_CASCADES; ++i)
+        if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
+    return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
+                            "the last synchronisation are invalid", bits, (bits & ow::kStatusRowSyncTimeout) ? ": wave-pair rendezvous timed out" : "");
+}
+ow_status refuse_faulted(const ow_context *c, uint32_t layer_mask) {
+    if (c->maps_faulted & layer_mask)
+        return fail(OW_ERR_HIP, "layer mask 0x%x holds maps of a batch that reported a device-side failure (already returned by an earlier call); "
+                                "they stay invalid until a later batch has recomputed those layers (faulted: 0x%x)", layer_mask, c->maps_faulted);
     return OW_OK;
+}
+// hipStreamSynchronize + the device status word.  layer_mask: the array layers whose bytes the caller is about to hand to ITS caller (0 for a
+// bare ow_sync), refused while they are those of a faulted batch.
+ow_status sync_stream(ow_context *c, uint32_t layer_mask) {
+    OW_HIP(hipStreamSynchronize(c->stream));
+    if (ow_status st = consume_status(c); st != OW_OK) return st;
+    c->enqueued_since_sync = 0;  // everything enqueued so far has finished cleanly
+    return refuse_faulted(c, layer_mask);
 }
 
 }  // namespace
@@ -291,26 +311,18 @@ namespace ow {
 // The device status word WITHOUT synchronising: for a caller that has waited by other means (the group's gather waits on its own
 // copy events) and is about to hand out map bytes.  Same consumption / stickiness as sync_stream.
 ow_status poll_status(ow_context *c) {
-    if (c->status_host && *c->status_host != 0u) {
-        const uint32_t bits = *c->status_host;
-        *c->status_host = 0u;
-        c->maps_faulted = true;
-        for (int i = 0; i < OW_MAX_CASCADES; ++i)
-            if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
-        return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x): the maps of the batches enqueued since the last "
-                                "synchronisation are invalid", bits);
-    }
-    if (c->maps_faulted) return fail(OW_ERR_HIP, "the maps are those of a batch that reported a device-side failure; they stay invalid until the next batch has been enqueued");
-    return OW_OK;
+    if (ow_status st = consume_status(c); st != OW_OK) return st;
+    return refuse_faulted(c, (1u << c->cascades) - 1u);
 }
 }  // namespace ow
 namespace {
 
+// every field finite -- also AFTER the narrowing of the push-constant pack (an FP64 value beyond FP32's range would reach the kernels as inf)
 bool finite_record(const ow_cascade_params &p) {
-    const float f[] = {p.tile_length[0], p.tile_length[1], p.wind_speed, p.wind_direction, p.fetch_length, p.swell, p.spread, p.detail,
-                       p.whitecap, p.foam_amount};
-    for (float v : f)
-        if (!std::isfinite(v)) return false;
+    const double f[] = {p.tile_length[0], p.tile_length[1], p.wind_speed, p.wind_direction, p.fetch_length, p.swell, p.spread, p.detail,
+                        p.whitecap, p.foam_amount, p.displacement_scale, p.normal_scale};
+    for (double v : f)
+        if (!std::isfinite(v) || !std::isfinite((float)v)) return false;
     return std::isfinite(p.time) && std::isfinite(p.foam_grow_rate) && std::isfinite(p.foam_decay_rate);
 }
 
@@ -344,26 +356,30 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
     // everything is validated before anything is launched: a bad record must not leave the batch half enqueued
     for (int i = 0; i < count; ++i)
         if (ow_status st = validate_record(params[idx[i]], idx[i]); st != OW_OK) return st;
-    c->maps_faulted = false;  // a new batch recomputes the maps (the foam state a faulted batch left behind is the caller's to restore)
     for (int i = 0; i < count; ++i) {
+        // a new batch recomputes THESE layers' maps (the foam state a faulted batch left behind is the caller's to restore); the other
+        // layers keep what they hold, marks included
+        c->maps_faulted &= ~(1u << idx[i]);
+        c->enqueued_since_sync |= 1u << idx[i];
         ow_cascade_params &p = params[idx[i]];
         if (p.should_generate_spectrum) {  // :68-72
-            // the exported setters clamp these two (wave_cascade_parameters.gd:15,20: max(0.0001, value)); a C caller has no setter
-            const float wind_speed = std::max(p.wind_speed, 1e-4f), fetch_length = std::max(p.fetch_length, 1e-4f);
-            const double F = (double)fetch_length * 1e3;
+            // the exported setters clamp these two (wave_cascade_parameters.gd:15,20: max(0.0001, value), FP64); a C caller has no setter.
+            // Everything up to the pack is FP64, as in GDScript (wave_generator.gd:69-71); the narrowing is the pack's (render_context.gd:134)
+            const double wind_speed = std::max(p.wind_speed, 1e-4), fetch_length = std::max(p.fetch_length, 1e-4);
+            const double F = fetch_length * 1e3;
             ow::SpectrumPC pc;
             pc.seed_x = p.spectrum_seed[0];
             pc.seed_y = p.spectrum_seed[1];
             pc.tile_x = p.tile_length[0];
             pc.tile_y = p.tile_length[1];
-            pc.alpha = (float)ow_jonswap_alpha((double)wind_speed, F);
-            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency((double)wind_speed, F);
-            pc.wind_speed = wind_speed;
-            pc.angle = (float)((double)p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
+            pc.alpha = (float)ow_jonswap_alpha(wind_speed, F);
+            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency(wind_speed, F);
+            pc.wind_speed = (float)wind_speed;
+            pc.angle = (float)(p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
             pc.depth = c->depth;
-            pc.swell = p.swell;
-            pc.detail = p.detail;
-            pc.spread = p.spread;
+            pc.swell = (float)p.swell;
+            pc.detail = (float)p.detail;
+            pc.spread = (float)p.spread;
             OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
             p.should_generate_spectrum = 0;
         }
@@ -371,7 +387,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         cf.tile_x = p.tile_length[0];
         cf.tile_y = p.tile_length[1];
         cf.time = (float)p.time;  // push constants are FP32 (render_context.gd:131-134)
-        cf.whitecap = p.whitecap;
+        cf.whitecap = (float)p.whitecap;
         cf.foam_grow_rate = (float)p.foam_grow_rate;
         cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
         cf.cascade = idx[i];
@@ -417,26 +433,28 @@ const char *ow_last_error(void) { return g_last_error.c_str(); }
 int32_t ow_abi_version(void) { return OW_ABI_VERSION; }
 
 double ow_jonswap_alpha(double wind_speed, double fetch_length_m) {  // wave_generator.gd:116-117
-    return 0.076 * std::pow(wind_speed * wind_speed / (fetch_length_m * kHostG), 0.22);
+    return 0.076 * std::pow(std::pow(wind_speed, 2.0) / (fetch_length_m * kHostG), 0.22);  // `wind_speed**2` is pow() in GDScript
 }
 double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_m) {  // wave_generator.gd:120-121
     return 22.0 * std::pow(kHostG * kHostG / (wind_speed * fetch_length_m), 1.0 / 3.0);
 }
 
+static_assert(sizeof(ow_cascade_params) == 128 && offsetof(ow_cascade_params, displacement_scale) == 8 && offsetof(ow_cascade_params, spectrum_seed) == 88 &&
+                  offsetof(ow_cascade_params, time) == 104, "ow_cascade_params layout (ABI 4): the C#, ctypes and C++ mirrors are written against it");
 void ow_cascade_params_default(ow_cascade_params *p) {  // wave_cascade_parameters.gd:7-42
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
     p->tile_length[0] = p->tile_length[1] = 50.0f;
-    p->displacement_scale = 1.0f;
-    p->normal_scale = 1.0f;
-    p->wind_speed = 20.0f;
-    p->wind_direction = 0.0f;
-    p->fetch_length = 550.0f;
-    p->swell = 0.8f;
-    p->spread = 0.2f;
-    p->detail = 1.0f;
-    p->whitecap = 0.5f;
-    p->foam_amount = 5.0f;
+    p->displacement_scale = 1.0;
+    p->normal_scale = 1.0;
+    p->wind_speed = 20.0;
+    p->wind_direction = 0.0;
+    p->fetch_length = 550.0;
+    p->swell = 0.8;
+    p->spread = 0.2;
+    p->detail = 1.0;
+    p->whitecap = 0.5;
+    p->foam_amount = 5.0;
     p->should_generate_spectrum = 1;
 }
 
@@ -599,8 +617,8 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
     for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
         ow_cascade_params &p = params[i];
         p.time += delta;
-        p.foam_grow_rate = delta * (double)p.foam_amount * 7.5;
-        const double d = 10.0 - (double)p.foam_amount;
+        p.foam_grow_rate = delta * p.foam_amount * 7.5;
+        const double d = 10.0 - p.foam_amount;
         p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
         c->pass_parameters[i] = p;        // :108 -- a copy: `params` is not touched after this call returns
         p.should_generate_spectrum = 0;   // consumed: the armed copy carries it until the cascade is processed (:72)
@@ -677,8 +695,8 @@ void advance_tick(double delta, ow_cascade_params *params, int count, float *tim
     for (int i = 0; i < count; ++i) {
         ow_cascade_params &p = params[count - 1 - i];
         p.time += delta;
-        p.foam_grow_rate = delta * (double)p.foam_amount * 7.5;
-        const double d = 10.0 - (double)p.foam_amount;
+        p.foam_grow_rate = delta * p.foam_amount * 7.5;
+        const double d = 10.0 - p.foam_amount;
         p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
         time_out[i] = (float)p.time;
     }
@@ -693,7 +711,7 @@ ow::FrameArgs run_frame_args(const ow_cascade_params *params, int count) {
         ow::CascadeFrame &cf = args.c[i];
         cf.tile_x = p.tile_length[0];
         cf.tile_y = p.tile_length[1];
-        cf.whitecap = p.whitecap;
+        cf.whitecap = (float)p.whitecap;
         cf.foam_grow_rate = (float)p.foam_grow_rate;
         cf.foam_decay = expf(-(float)p.foam_decay_rate);
         cf.cascade = count - 1 - i;
@@ -716,6 +734,8 @@ void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_para
     }
     c->pass_count = count;
     c->pass_num_cascades_remaining = 0;
+    c->maps_faulted &= ~((1u << count) - 1u);  // (as enqueue(): the run recomputed layers 0 .. count - 1)
+    c->enqueued_since_sync |= (1u << count) - 1u;
     c->last_args = args;
     c->last_count = last_batch;
     c->last_family = family;
@@ -851,7 +871,7 @@ int32_t ow_cascades_remaining(const ow_context *c) { return c ? c->pass_num_casc
 ow_status ow_sync(ow_context *c) {
     if (!c) return fail(OW_ERR_INVALID, "null context");
     OW_HIP(hipSetDevice(c->device));
-    return sync_stream(c, false);
+    return sync_stream(c, 0u);
 }
 
 ow_status ow_get_device_ptrs(ow_context *c, void **disp, void **norm, size_t *stride) {
@@ -979,7 +999,7 @@ ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {
     const size_t bytes = plane(c) * sizeof(ow::u16x4);
     if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
     if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
-    return sync_stream(c);
+    return sync_stream(c, 1u << cascade);
 }
 
 ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
@@ -1043,7 +1063,7 @@ ow_status ow_readback_wait(ow_context *c, int32_t cascade, const void **disp, co
     c->copy_pending[cascade] = false;
     if (*c->status_host != 0u) {  // a frame kernel reported a failure: the bytes that landed are not maps
         c->readback_faulted |= 1u << cascade;  // (copy_pending was just cleared: mark this layer by hand, the others are marked by sync_stream)
-        (void)sync_stream(c);
+        (void)sync_stream(c, 0u);
     }
     if ((c->readback_faulted >> cascade) & 1u) {  // every layer of the faulted batch fails, not only the first one waited for
         c->readback_faulted &= ~(1u << cascade);
@@ -1082,7 +1102,7 @@ ow_status ow_sample_surface(ow_context *c, const float *xz, int32_t count, const
     OW_HIP(hipMemcpyAsync(c->query_xz, xz, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     OW_HIP(ow::launch_sample_surface(c->n, num_cascades, c->buf, c->query_xz, count, sc, c->query_out, c->stream));
     OW_HIP(hipMemcpyAsync(out, c->query_out, (size_t)count * sizeof(ow::SurfaceSample), hipMemcpyDeviceToHost, c->stream));
-    return sync_stream(c);
+    return sync_stream(c, (1u << num_cascades) - 1u);
 }
 
 ow_status ow_set_normal_map(ow_context *c, int32_t cascade, const void *norm) {
@@ -1110,7 +1130,7 @@ ow_status ow_get_maps_f32(ow_context *c, int32_t cascade, float *out) {
     if (!out) return fail(OW_ERR_INVALID, "null output");
     OW_HIP(hipSetDevice(c->device));
     OW_HIP(hipMemcpyAsync(out, c->buf.f32 + cascade * plane(c) * 8, plane(c) * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    return sync_stream(c);
+    return sync_stream(c, 1u << cascade);
 }
 
 ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omega) {

@@ -50,9 +50,11 @@ class MapGatherer:
         if mode == "all" or rank == root:
             self.out = torch.empty((world,) + shape, dtype=disp.dtype, device=disp.device)
         self.work = None
-        self.fallback = None  # set when the backend refused gather-to-root and the exchange fell back to an all-gather
+        self.fallback = None  # set (at construction, by all ranks together) when the backend has no gather-to-root: all-gather instead
         self.bytes_sent = self.snap.numel() * self.snap.element_size()
         self.bytes_received = (self.out.numel() * self.out.element_size()) if self.out is not None else 0
+        if mode == "root" and world > 1 and dist.is_initialized():
+            self._agree_on_gather_support()
 
     # -- one gather: snapshot now (in compute-stream order), bytes move on the side stream --
     def begin(self):
@@ -87,18 +89,37 @@ class MapGatherer:
             # flat views: the concatenating form of all_gather_into_tensor, accepted by both RCCL and gloo
             return dist.all_gather_into_tensor(self.out.view(u8).view(-1), self.snap.view(u8).view(-1), async_op=async_op)
         parts = [self.out[r].view(u8) for r in range(self.world)] if self.rank == self.root else None
+        return dist.gather(self.snap.view(u8), gather_list=parts, dst=self.root, async_op=async_op)
+
+    _UNSUPPORTED = ("not supported", "not implemented", "does not support", "unsupported", "no backend type associated")
+
+    def _agree_on_gather_support(self):
+        """Decided ONCE, before any map travels, and by ALL ranks together: a tiny gather-to-root probes the backend (a backend without
+        gather refuses at the call, on every rank alike: NotImplementedError, or a RuntimeError that says "not supported"), then a MIN
+        all-reduce of the outcome makes the ranks agree -- no rank can end up issuing all_gather while another issues gather.  Any other
+        exception is a real failure and is raised, not masked."""
+        torch, dist = self.torch, self.dist
+        probe = torch.zeros(8, dtype=torch.uint8, device=self.snap.device)
+        parts = [torch.empty_like(probe) for _ in range(self.world)] if self.rank == self.root else None
+        ok, why = 1, ""
         try:
-            return dist.gather(self.snap.view(u8), gather_list=parts, dst=self.root, async_op=async_op)
-        except (RuntimeError, NotImplementedError) as e:
-            # A backend without gather (every rank sees the refusal at the same call, before anything was sent): the exchange
-            # degrades to the all-gather for the rest of the run -- N times the receive volume, said so in `fallback` -- rather
-            # than costing the run.
-            self.fallback = f"gather-to-root refused by the backend ({type(e).__name__}: {str(e)[:120]}): all_gather instead"
-            self.mode = "all"
-            if self.out is None:
-                self.out = self.torch.empty((self.world,) + tuple(self.snap.shape), dtype=self.snap.dtype, device=self.snap.device)
-            self.bytes_received = self.out.numel() * self.out.element_size()
-            return dist.all_gather_into_tensor(self.out.view(u8).view(-1), self.snap.view(u8).view(-1), async_op=async_op)
+            dist.gather(probe, gather_list=parts, dst=self.root)
+        except NotImplementedError as e:
+            ok, why = 0, f"{type(e).__name__}: {str(e)[:120]}"
+        except RuntimeError as e:
+            if not any(m in str(e).lower() for m in self._UNSUPPORTED):
+                raise
+            ok, why = 0, f"{type(e).__name__}: {str(e)[:120]}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.snap.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return
+        # the exchange degrades to the all-gather for the whole run -- N times the receive volume, said so in `fallback`
+        self.fallback = f"gather-to-root refused by the backend ({why or 'on another rank'}): all_gather instead"
+        self.mode = "all"
+        if self.out is None:
+            self.out = torch.empty((self.world,) + tuple(self.snap.shape), dtype=self.snap.dtype, device=self.snap.device)
+        self.bytes_received = self.out.numel() * self.out.element_size()
 
     def wait(self):
         """host-level: returns when the most recent gather's bytes are in `out`"""

@@ -25,10 +25,12 @@ extern "C" {
 
 #define OW_MAX_CASCADES 8 /* MAX_CASCADES, assets/shaders/spatial/water.gdshader:8 */
 #define OW_MAX_DEVICES 8  /* the GPUs of one node */
-#define OW_ABI_VERSION 3 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word;
+#define OW_ABI_VERSION 4 /* 2: ow_update copies the records (no borrowed pointer), ow_set/get_cascade_params, device status word;
                             3: ow_group_* (cascades sharded over several devices, gather into the consumer's arrays), records are
                                validated on the way in (ow_update / ow_set_cascade_params), sticky device-side failures,
-                               ow_export_maps / ow_import_buffer (dma-buf hand-off) */
+                               ow_export_maps / ow_import_buffer (dma-buf hand-off);
+                            4: the scalar fields of ow_cascade_params are FP64, as a GDScript caller holds them, and are narrowed
+                               where the reference narrows them (the push-constant pack) -- the record is 128 bytes */
 
 typedef enum ow_status {
     OW_OK = 0,
@@ -41,31 +43,33 @@ typedef enum ow_status {
 } ow_status;
 
 /* WaveCascadeParameters -- assets/water/wave_cascade_parameters.gd:7-42.
- * Field meaning, units and defaults are the reference's.  GDScript floats are FP64 and are narrowed to FP32 when
- * packed into push constants (assets/render_context.gd:131-134); the exported parameters are FP32 here, i.e. narrowed
- * one step earlier: the JONSWAP alpha / peak frequency and the degree -> radian conversion are evaluated in FP64 from
- * the FP32 fields, which can differ from the reference's FP64-input evaluation in the last FP32 bit (inside the tested
- * tolerance; not bit-exact).  `time`, `foam_*_rate` and `should_generate_spectrum` are runtime state: ow_update
- * advances them inside the caller's struct (wave_generator.gd:103-106) during the call. */
+ * Field meaning, units and defaults are the reference's, and so are the TYPES a GDScript caller holds: every exported
+ * `float` of the resource is FP64 there and is narrowed to FP32 only when it is packed into a push constant
+ * (assets/render_context.gd:131-134, encode_float), AFTER the host math that uses it -- JONSWAP alpha / peak frequency
+ * (wave_generator.gd:69-70,116-121), deg_to_rad (:71), foam_grow_rate / foam_decay_rate (:104-106).  So the scalar
+ * parameters are `double` here (ABI 4) and the library narrows them exactly where the reference does; a caller that
+ * holds FP32 values simply widens them.  `tile_length` is a Vector2, whose components are FP32 in Godot (real_t) and
+ * stay `float`.  `time`, `foam_*_rate` and `should_generate_spectrum` are runtime state: ow_update advances them inside
+ * the caller's struct (wave_generator.gd:103-106) during the call. */
 typedef struct ow_cascade_params {
-    float tile_length[2];     /* metres covered by the tile, default (50, 50)              :7  */
-    float displacement_scale; /* consumer-side only, default 1.0                           :9  */
-    float normal_scale;       /* consumer-side only, default 1.0                           :11 */
-    float wind_speed;         /* m/s, default 20; values below 1e-4 are used as 1e-4 (the setter's clamp) :15 */
-    float wind_direction;     /* degrees, default 0                                        :17 */
-    float fetch_length;       /* km, default 550; values below 1e-4 are used as 1e-4          :20 */
-    float swell;              /* [0,2], default 0.8                                        :22 */
-    float spread;             /* [0,1], default 0.2                                        :25 */
-    float detail;             /* [0,1], default 1.0                                        :28 */
-    float whitecap;           /* [0,2], default 0.5                                        :32 */
-    float foam_amount;        /* [0,10], default 5.0                                       :34 */
-    int32_t spectrum_seed[2]; /* Vector2i, offsets the hash lattice                        :37 */
-    int32_t should_generate_spectrum; /* dirty flag, default 1                            :38 */
+    float tile_length[2];      /* Vector2 (FP32 components): metres covered by the tile, default (50, 50)     :7  */
+    double displacement_scale; /* consumer-side only, default 1.0                                             :9  */
+    double normal_scale;       /* consumer-side only, default 1.0                                             :11 */
+    double wind_speed;         /* m/s, default 20; values below 1e-4 are used as 1e-4 (the setter's clamp)    :15 */
+    double wind_direction;     /* degrees, default 0                                                          :17 */
+    double fetch_length;       /* km, default 550; values below 1e-4 are used as 1e-4                         :20 */
+    double swell;              /* [0,2], default 0.8                                                          :22 */
+    double spread;             /* [0,1], default 0.2                                                          :25 */
+    double detail;             /* [0,1], default 1.0                                                          :28 */
+    double whitecap;           /* [0,2], default 0.5                                                          :32 */
+    double foam_amount;        /* [0,10], default 5.0                                                         :34 */
+    int32_t spectrum_seed[2];  /* Vector2i, offsets the hash lattice                                          :37 */
+    int32_t should_generate_spectrum; /* dirty flag, default 1                                              :38 */
     int32_t reserved;
-    double time;              /* seconds; water.gd:32 starts cascade i at 120 + PI*i        :40 */
-    double foam_grow_rate;    /* set by ow_update: delta * foam_amount * 7.5                :41 */
-    double foam_decay_rate;   /* set by ow_update: delta * max(0.5, 10 - foam_amount)*1.15  :42 */
-} ow_cascade_params;
+    double time;               /* seconds; water.gd:32 starts cascade i at 120 + PI*i                         :40 */
+    double foam_grow_rate;     /* set by ow_update: delta * foam_amount * 7.5                                 :41 */
+    double foam_decay_rate;    /* set by ow_update: delta * max(0.5, 10 - foam_amount)*1.15                   :42 */
+} ow_cascade_params;           /* 128 bytes */
 
 /* Creation parameters -- replaces `wave_generator.map_size = N; wave_generator.init_gpu(C)`
  * (assets/water/water.gd:89-91, wave_generator.gd:8,17). */
@@ -168,9 +172,10 @@ int32_t ow_cascades_remaining(const ow_context *ctx);
  * ow_get_maps_f32, ow_readback_wait, ow_sample_surface -- into OW_ERR_HIP.  The maps of the batches enqueued since the previous
  * synchronisation are then invalid, and so is the foam state they left behind (restore it with ow_set_normal_map).  The word
  * itself is consumed by the first call that sees it (ow_sync reports it once), but the failure is sticky for everything that
- * hands out map bytes: ow_get_maps, ow_get_maps_f32, ow_sample_surface and the ow_readback_wait of EVERY layer whose copy
- * was in flight keep returning OW_ERR_HIP until the next batch has been enqueued (or, for a layer's readback, until its next
- * ow_readback_begin).  The device-side wait is bounded by wall time (20 ms), and the report is a plain store + system fence
+ * hands out map bytes, LAYER BY LAYER: ow_get_maps / ow_get_maps_f32 of a layer that one of those batches recomputed,
+ * ow_sample_surface over such a layer, and the ow_readback_wait of EVERY layer whose copy was in flight keep returning OW_ERR_HIP
+ * until a later batch has recomputed THAT layer (the reference's schedule enqueues one cascade per ow_process: the other layers
+ * still hold the faulted batch's bytes) or, for a layer's readback, until its next ow_readback_begin.  The device-side wait is bounded by wall time (20 ms), and the report is a plain store + system fence
  * into page-locked host memory: it needs no PCIe atomics. */
 ow_status ow_sync(ow_context *ctx);
 
@@ -274,7 +279,10 @@ ow_context *ow_group_context(ow_group *group, int32_t shard);
 /* ow_update / ow_process / ow_update_all / ow_run over the whole group: `params` holds the records of ALL cascades in global
  * order (count == ow_group_num_cascades), shard s works on its slice.  ow_group_process keeps the reference's order -- one armed
  * cascade per call, highest global index first (wave_generator.gd:56-63).  The first failing shard's status is returned; its
- * message is ow_last_error(). */
+ * message is ow_last_error().  Everything a caller can get wrong is refused before any shard starts (OW_ERR_INVALID leaves no
+ * trace).  There is no rollback beyond that: if a shard fails with OW_ERR_HIP / OW_ERR_NOMEM the other shards have already advanced
+ * (their slices of `params` carry the new times) and the group is no longer in step -- destroy it and rebuild from the parameter
+ * objects and the gathered normal maps (ow_set_normal_map), the same state a re-sharding uses. */
 ow_status ow_group_update(ow_group *group, double delta, ow_cascade_params *params, int32_t count);
 ow_status ow_group_process(ow_group *group);
 ow_status ow_group_update_all(ow_group *group, double delta, ow_cascade_params *params, int32_t count);
@@ -283,6 +291,11 @@ int32_t ow_group_cascades_remaining(const ow_group *group);
 /* ow_sync of every shard (and of an outstanding gather) */
 ow_status ow_group_sync(ow_group *group);
 
+/* ow_group_gather_wait waits for EVERY shard's copy, then returns the first failure.  A shard whose kernels had reported a device-side
+ * failure (the status word of ow_sync) when its layers landed makes the call return OW_ERR_HIP, and its layers of the gathered arrays
+ * stay marked: ow_group_get_maps of those layers and ow_group_sample_surface over them keep returning OW_ERR_HIP until a later gather
+ * of that shard has landed cleanly (the device pointers of ow_group_get_device_ptrs stay what they are: a caller that reads through
+ * them takes gather_wait's status as the verdict on their contents). */
 ow_status ow_group_gather_begin(ow_group *group);
 ow_status ow_group_gather_wait(ow_group *group);
 /* Duration (ms, begin of the first to end of the last copy, per shard, maximum over shards) and volume of the most recent completed

@@ -32,7 +32,7 @@ int owo_num_threads(void) {
 /* ---- host math: assets/water/wave_generator.gd:116-121 (GDScript float = FP64) ---- */
 double owo_jonswap_alpha(double wind_speed, double fetch_length_m) {
     const double g = 9.81;
-    return 0.076 * pow(wind_speed * wind_speed / (fetch_length_m * g), 0.22);
+    return 0.076 * pow(pow(wind_speed, 2.0) / (fetch_length_m * g), 0.22); /* `wind_speed**2`: GDScript's ** on floats is pow() */
 }
 
 double owo_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_m) {
@@ -451,8 +451,8 @@ void owo_generator_destroy(owo_generator *g) {
 void owo_generator_advance(owo_cascade_params *p, int count, double delta) {
     for (int i = 0; i < count; ++i) {
         p[i].time += delta;
-        p[i].foam_grow_rate = delta * (double)p[i].foam_amount * 7.5;
-        double d = 10.0 - (double)p[i].foam_amount;
+        p[i].foam_grow_rate = delta * p[i].foam_amount * 7.5;
+        double d = 10.0 - p[i].foam_amount;
         p[i].foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
     }
 }
@@ -464,22 +464,23 @@ void owo_generator_update_cascade(owo_generator *g, int c, owo_cascade_params *p
     float *half0 = g->fft + nn * 4 * 2 * 2 * c, *half1 = half0 + nn * 4 * 2;
     if (p->should_generate_spectrum) {
         owo_spectrum_pc pc;
-        /* render_context.gd:131-134 narrows every float to FP32 when packing */
-        double F = (double)p->fetch_length * 1e3;
+        /* wave_generator.gd:69-71: FP64 host math on the FP64 parameters; render_context.gd:131-134 narrows every float to FP32
+         * when packing -- and only there */
+        double F = p->fetch_length * 1e3;
         pc.seed[0] = p->spectrum_seed[0]; pc.seed[1] = p->spectrum_seed[1];
         pc.tile_length[0] = p->tile_length[0]; pc.tile_length[1] = p->tile_length[1];
-        pc.alpha = (float)owo_jonswap_alpha((double)p->wind_speed, F);
-        pc.peak_frequency = (float)owo_jonswap_peak_angular_frequency((double)p->wind_speed, F);
-        pc.wind_speed = p->wind_speed;
-        pc.angle = (float)((double)p->wind_direction * (3.14159265358979323846 / 180.0)); /* deg_to_rad */
+        pc.alpha = (float)owo_jonswap_alpha(p->wind_speed, F);
+        pc.peak_frequency = (float)owo_jonswap_peak_angular_frequency(p->wind_speed, F);
+        pc.wind_speed = (float)p->wind_speed;
+        pc.angle = (float)(p->wind_direction * (3.14159265358979323846 / 180.0)); /* deg_to_rad */
         pc.depth = g->depth;
-        pc.swell = p->swell; pc.detail = p->detail; pc.spread = p->spread;
+        pc.swell = (float)p->swell; pc.detail = (float)p->detail; pc.spread = (float)p->spread;
         owo_spectrum_compute(g->n, &pc, spectrum);
         p->should_generate_spectrum = 0;
     }
     owo_spectrum_modulate(g->n, p->tile_length[0], p->tile_length[1], g->depth, (float)p->time, spectrum, half0);
     owo_ifft2(g->n, g->table, half0, half1);
-    owo_unpack(g->n, half1, p->whitecap, (float)p->foam_grow_rate, (float)p->foam_decay_rate,
+    owo_unpack(g->n, half1, (float)p->whitecap, (float)p->foam_grow_rate, (float)p->foam_decay_rate,
                g->disp + nn * 4 * c, g->normal + nn * 4 * c, g->f32 + nn * 8 * c);
 }
 

@@ -97,12 +97,13 @@ void owo_unpack(int n, const float *fft_half1, float whitecap, float foam_grow_r
 
 /* ---- WaveGenerator restatement (wave_generator.gd:17-109) -------------------------- */
 
-/* wave_cascade_parameters.gd:7-42 */
+/* wave_cascade_parameters.gd:7-42.  GDScript `float` members are FP64 and stay FP64 until render_context.gd:131-134 narrows them
+ * into the push constant (after the host math of wave_generator.gd:69-71,104-106); tile_length is a Vector2 (FP32 components). */
 typedef struct {
     float tile_length[2];
-    float displacement_scale, normal_scale;
-    float wind_speed, wind_direction /* deg */, fetch_length /* km */;
-    float swell, spread, detail, whitecap, foam_amount;
+    double displacement_scale, normal_scale;
+    double wind_speed, wind_direction /* deg */, fetch_length /* km */;
+    double swell, spread, detail, whitecap, foam_amount;
     int32_t spectrum_seed[2];
     int32_t should_generate_spectrum;
     double time;

@@ -44,14 +44,22 @@ def test_header_is_plain_c():
 
 
 def test_struct_layout_matches_ctypes(lib):
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "ocean_waves.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "ocean_waves.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
            'sizeof(ow_cascade_params), offsetof(ow_cascade_params, spectrum_seed), offsetof(ow_cascade_params, time),'
-           'sizeof(ow_config), offsetof(ow_config, stream), offsetof(ow_config, flags));return 0;}\n')
+           'sizeof(ow_config), offsetof(ow_config, stream), offsetof(ow_config, flags), offsetof(ow_cascade_params, displacement_scale),'
+           'offsetof(ow_cascade_params, wind_speed), offsetof(ow_cascade_params, foam_amount), OW_ABI_VERSION);return 0;}\n')
     exe = "/tmp/ow_layout_check"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     P, Cfg = _lib.ow_cascade_params, _lib.ow_config
-    assert got == [C.sizeof(P), P.spectrum_seed.offset, P.time.offset, C.sizeof(Cfg), Cfg.stream.offset, Cfg.flags.offset]
+    assert got == [C.sizeof(P), P.spectrum_seed.offset, P.time.offset, C.sizeof(Cfg), Cfg.stream.offset, Cfg.flags.offset,
+                   P.displacement_scale.offset, P.wind_speed.offset, P.foam_amount.offset, lib.ow_abi_version()]
+    # ABI 4: the scalar parameters are FP64 (a GDScript float), the record is 128 bytes; tile_length stays a pair of FP32 (Vector2)
+    assert got[0] == 128 and got[-1] == 4 and P.tile_length.size == 8 and P.wind_speed.size == 8 and P.foam_amount.size == 8
+    # ... and the oracle's record carries the same types (the checker narrows where the reference does, not earlier)
+    from oracle import oracle as O
+    for name in ("wind_speed", "wind_direction", "fetch_length", "swell", "spread", "detail", "whitecap", "foam_amount"):
+        assert getattr(O.CascadeParams, name).size == 8, name
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "ocean_waves.h"\nint main(void){printf("%zu %zu %zu %zu %zu %d\\n",'
            'sizeof(ow_group_config), offsetof(ow_group_config, device_ids), offsetof(ow_group_config, root),'
            'offsetof(ow_group_config, flags), offsetof(ow_group_config, normal_map), OW_MAX_DEVICES);return 0;}\n')
@@ -66,14 +74,15 @@ def test_defaults_match_reference(lib):
     lib.ow_cascade_params_default(C.byref(p))
     # wave_cascade_parameters.gd:7-38
     assert tuple(p.tile_length) == (50.0, 50.0) and p.wind_speed == 20.0 and p.fetch_length == 550.0
-    assert abs(p.swell - 0.8) < 1e-7 and abs(p.spread - 0.2) < 1e-7 and p.detail == 1.0
+    assert p.swell == 0.8 and p.spread == 0.2 and p.detail == 1.0   # the FP64 literals of the .gd file, not their FP32 roundings
+    assert p.displacement_scale == 1.0 and p.normal_scale == 1.0 and p.wind_direction == 0.0
     assert p.whitecap == 0.5 and p.foam_amount == 5.0 and p.should_generate_spectrum == 1 and p.time == 0.0
 
 
 def test_jonswap_host_math(lib):
     # wave_generator.gd:116-121 evaluated by hand in FP64
     U, F, g = 20.0, 550e3, 9.81
-    assert lib.ow_jonswap_alpha(U, F) == pytest.approx(0.076 * (U * U / (F * g)) ** 0.22, rel=1e-15)
+    assert lib.ow_jonswap_alpha(U, F) == pytest.approx(0.076 * (U ** 2 / (F * g)) ** 0.22, rel=1e-15)
     assert lib.ow_jonswap_peak_angular_frequency(U, F) == pytest.approx(22.0 * (g * g / (U * F)) ** (1.0 / 3.0), rel=1e-15)
 
 

@@ -52,7 +52,8 @@ def _worker(rank, world, port, n, per_rank, frames, mode, out_dir):
         dist.gather = no_gather
     gat = sharding.MapGatherer(torch, dist, world, rank, disp, norm, per_rank, mode=mode, root=0)
     assert gat.bytes_sent == 2 * per_rank * n * n * 8
-    assert gat.bytes_received == (world * gat.bytes_sent if (mode == "all" or rank == 0) else 0)
+    # (a refused gather-to-root is found out at construction, by all ranks together: every rank then receives everything)
+    assert gat.bytes_received == (world * gat.bytes_sent if (mode == "all" or rank == 0 or refuse) else 0)
     for f in range(frames):
         g.update_all(UPDATE_DELTA)
         for i in range(per_rank):
@@ -92,6 +93,46 @@ def test_two_rank_gloo_shard_and_gather(tmp_path, per_rank, mode):
     for c in range(world * per_rank):
         assert np.array_equal(disp[c], g.displacement(c)), c
         assert np.array_equal(norm[c], g.normal(c)), c
+
+
+def test_gather_support_is_agreed_once_and_real_failures_are_not_masked():
+    """The mode is settled at construction by a probe + a MIN all-reduce (every rank takes the same branch); only a refusal
+    ("not supported" / NotImplementedError) degrades to the all-gather -- any other error of the probe is raised."""
+    import torch
+    from godotoceanwaves_amd import sharding
+
+    class FakeDist:
+        class ReduceOp:
+            MIN = "min"
+
+        def __init__(self, exc, others_ok=True):
+            self.exc, self.others_ok, self.calls = exc, others_ok, []
+
+        def is_initialized(self):
+            return True
+
+        def gather(self, t, gather_list=None, dst=0, async_op=False):
+            self.calls.append("gather")
+            if self.exc:
+                raise self.exc
+
+        def all_reduce(self, flag, op=None):
+            self.calls.append("all_reduce")
+            if not self.others_ok:
+                flag.zero_()
+
+    d = torch.zeros((2, 8, 8, 4), dtype=torch.float16)
+    ok = FakeDist(None)
+    g = sharding.MapGatherer(torch, ok, 2, 1, d, d, 1, mode="root")
+    assert g.mode == "root" and g.fallback is None and g.out is None and ok.calls == ["gather", "all_reduce"]
+    for exc in (NotImplementedError("no gather here"), RuntimeError("ProcessGroupX does not support gather")):
+        g = sharding.MapGatherer(torch, FakeDist(exc), 2, 1, d, d, 1, mode="root")
+        assert g.mode == "all" and "all_gather instead" in g.fallback and g.out is not None and g.bytes_received == 2 * g.bytes_sent
+    # this rank's probe went through, another rank's was refused: the all-reduce carries the decision
+    g = sharding.MapGatherer(torch, FakeDist(None, others_ok=False), 2, 1, d, d, 1, mode="root")
+    assert g.mode == "all" and "on another rank" in g.fallback
+    with pytest.raises(RuntimeError, match="connection reset"):
+        sharding.MapGatherer(torch, FakeDist(RuntimeError("connection reset by peer")), 2, 1, d, d, 1, mode="root")
 
 
 def test_gatherer_argument_errors():
