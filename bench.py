@@ -318,7 +318,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
         # (avg_launch_ms_events): those brackets include the event packets' own handling and scatter by +-5 % from visit to visit.
         # (p1 / p2 below are the one-launch-per-pass kernels of the same tick, probed after.)
         GROUP = max(1, group_depth)
-        dom = MERGED_KERNEL[launch_mode]
+        dom = MERGED_KERNEL[launch_mode] + ("_split" if (n == 2048 and launch_mode == "tick_pairs_compact") else "")  # (rows that span two waves)
         # (foam is read before the first and written after the last of a group's ticks only: 4 B/texel less for each tick in between)
         T = probe - 1
         groups = -(-T // GROUP)

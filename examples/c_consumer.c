@@ -3,7 +3,9 @@
  * finished layer to the host asynchronously (what RenderingDevice.texture_update would consume), sample the surface on the
  * device, and print checksums.
  *   gcc -O2 -std=c99 -Iinclude examples/c_consumer.c -o c_consumer -Lgodotoceanwaves_amd -locean_waves \
- *       -Wl,-rpath,$PWD/godotoceanwaves_amd -Wl,-rpath-link,/opt/rocm/lib -lm && ./c_consumer [map_size [frames]] */
+ *       -Wl,-rpath,$PWD/godotoceanwaves_amd -Wl,-rpath-link,/opt/rocm/lib -lm && ./c_consumer [map_size [frames [dump_prefix]]]
+ * dump_prefix: every layer handed off is also written to <dump_prefix><layer>.bin (displacement bytes, then normal bytes; a later
+ * hand-off of the same layer replaces the file) -- the bytes texture_update would get, for the tests to hold to the fixtures. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -19,8 +21,19 @@ static uint64_t fnv1a(const void *data, size_t n) {
     return h;
 }
 
+static int dump_layer(const char *prefix, int layer, const void *d, const void *m, size_t bytes) {
+    char path[512];
+    if (!prefix) return 0;
+    snprintf(path, sizeof path, "%s%d.bin", prefix, layer);
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const int ok = fwrite(d, 1, bytes, f) == bytes && fwrite(m, 1, bytes, f) == bytes;
+    return fclose(f) == 0 && ok ? 0 : -1;
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 256, cascades = 3, frames = argc > 2 ? atoi(argv[2]) : 12;
+    const char *dump = argc > 3 ? argv[3] : NULL;
 
     ow_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -52,6 +65,7 @@ int main(int argc, char **argv) {
             const void *d, *m;
             if (ow_readback_wait(ctx, in_flight, &d, &m) != OW_OK) goto fail;
             sum ^= fnv1a(d, (size_t)n * n * 8) + 31 * fnv1a(m, (size_t)n * n * 8) + (uint64_t)in_flight;
+            if (dump_layer(dump, in_flight, d, m, (size_t)n * n * 8) != 0) { fprintf(stderr, "cannot write the dump\n"); ow_destroy(ctx); return 1; }
             ++handed;
         }
         const int layer = ow_cascades_remaining(ctx) - 1;
@@ -63,6 +77,7 @@ int main(int argc, char **argv) {
         const void *d, *m;
         if (ow_readback_wait(ctx, in_flight, &d, &m) != OW_OK) goto fail;
         sum ^= fnv1a(d, (size_t)n * n * 8) + 31 * fnv1a(m, (size_t)n * n * 8) + (uint64_t)in_flight;
+        if (dump_layer(dump, in_flight, d, m, (size_t)n * n * 8) != 0) { fprintf(stderr, "cannot write the dump\n"); ow_destroy(ctx); return 1; }
         ++handed;
     }
     {   /* what the water / sea-spray shaders would read along a line of 64 world points */

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "wave_generator.hpp"
 
@@ -22,6 +23,9 @@ static uint64_t fnv1a(const void *data, size_t n) {
 
 int main(int argc, char **argv) try {
     const int n = argc > 1 ? atoi(argv[1]) : 256, cascades = 3, frames = argc > 2 ? atoi(argv[2]) : 12;
+    // argv[3]: every layer the sink is handed is also written to <prefix><layer>.bin (displacement bytes, then normal bytes; a later
+    // hand-off of the same layer replaces the file): the bytes texture_update would get, for the tests to hold to the fixtures
+    const std::string dump = argc > 3 ? argv[3] : "";
     // the three cascades of the reference's main.tscn, seeds and time offsets as water.gd:31-32 assigns them
     const float tile[3] = {88.0f, 57.0f, 16.0f}, wind[3] = {10.0f, 5.0f, 20.0f}, dir[3] = {20.0f, 15.0f, 20.0f};
     const float fetch[3] = {150.0f, 150.0f, 550.0f}, spread[3] = {0.2f, 0.4f, 0.4f}, whitecap[3] = {0.5f, 0.5f, 0.25f}, foam[3] = {8.0f, 0.0f, 3.0f};
@@ -53,6 +57,10 @@ int main(int argc, char **argv) try {
     uint64_t sum = 0, pending = 0;
     int handed = 0;
     wave_generator.set_texture_update([&](const char *which, int layer, const void *bytes, size_t size) {
+        if (!dump.empty()) {
+            FILE *f = std::fopen((dump + std::to_string(layer) + ".bin").c_str(), std::strcmp(which, "displacement_map") == 0 ? "wb" : "ab");
+            if (!f || std::fwrite(bytes, 1, size, f) != size || std::fclose(f) != 0) throw Error(OW_ERR_INVALID, "cannot write the dump");
+        }
         if (std::strcmp(which, "displacement_map") == 0) {
             pending = fnv1a(bytes, size);
         } else {

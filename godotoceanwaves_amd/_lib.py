@@ -34,6 +34,11 @@ class ow_cascade_params(C.Structure):
                 ("foam_grow_rate", C.c_double), ("foam_decay_rate", C.c_double)]
 
 
+class ow_push_constants(C.Structure):
+    """the reference's three push-constant blocks of one cascade, as 32-bit words (ow_get_push_constants)"""
+    _fields_ = [("spectrum", C.c_uint32 * 16), ("modulate", C.c_uint32 * 8), ("unpack", C.c_uint32 * 4)]
+
+
 class ow_config(C.Structure):
     _fields_ = [("map_size", C.c_int32), ("num_cascades", C.c_int32), ("device_id", C.c_int32), ("depth", C.c_float),
                 ("stream", C.c_void_p), ("displacement_map", C.c_void_p), ("normal_map", C.c_void_p),
@@ -56,6 +61,7 @@ SIGNATURES = {
     "ow_set_cascade_params": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_cascade_params)]),
     "ow_get_cascade_params": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_cascade_params)]),
     "ow_debug_inject_fault": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "ow_get_push_constants": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_push_constants)]),
     "ow_process": (C.c_int, [C.c_void_p]),
     "ow_update_all": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32]),
     "ow_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),

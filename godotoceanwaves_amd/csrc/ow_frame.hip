@@ -54,7 +54,7 @@ static hipError_t launch1(int slots, int mode, const FrameArgs &args, const Devi
     }
     if constexpr (plan_split(N)) {
         if (fam == 3) {  // a row spans two waves: the split plan (one wave per parity, no rendezvous in pass 1)
-            launch(k_pass1c_split<N, OW_SPLIT_P1_ROWS>, dim3(blocks * (kWgRows / OW_SPLIT_P1_ROWS)), dim3(SplitGeo<N, OW_SPLIT_P1_ROWS>::kThreads), s, lt, buf, args);
+            launch(k_pass1c_split<N, OW_SPLIT_P1_ROWS>, dim3(blocks * (kWgRows / OW_SPLIT_P1_ROWS)), dim3(SplitGeo<N, OW_SPLIT_P1_ROWS>::kThreads), s, lt, buf, args, (Stamp *)nullptr);
             return hipGetLastError();
         }
     }
@@ -109,7 +109,8 @@ static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const De
     g.n2 = g.slots2 * (N / kWgRows);
     g.n1 = g.slots1 * (N / kWgRows);
     if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-    launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+    if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
+    else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
     return hipGetLastError();
 }
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----
@@ -127,6 +128,7 @@ static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const D
     return hipGetLastError();
 }
 bool tick_groups_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+bool tick_pairs_supported(int n) { return tick_groups_supported(n) || n == 2048; }  // (2048: k_tick_pair_c_split, one cascade per batch)
 int tick_group_pipe_blocks(int n, int slots) {
     return n == 256 ? TickPlan<256>::items_2_pipe(slots) : n == 512 ? TickPlan<512>::items_2_pipe(slots) : n == 1024 ? TickPlan<1024>::items_2_pipe(slots) : 0;
 }
@@ -138,6 +140,9 @@ hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &
         OW_GROUP(256)
         OW_GROUP(512)
         OW_GROUP(1024)
+        case 2048:  // tick pairs only (a row spans two waves: no tick groups at this size)
+            if (!g.pair_compact) return hipErrorInvalidValue;
+            return buf.f32 ? launch_pair_n<2048, true>(args, g, buf, s, lt) : launch_pair_n<2048, false>(args, g, buf, s, lt);
     }
 #undef OW_GROUP
     return hipErrorInvalidValue;

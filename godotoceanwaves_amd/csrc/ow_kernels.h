@@ -59,6 +59,7 @@ hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const
 // g.tbase2[j] + i) and / or pass 1 of g.d1 later ticks (times g.time1[j][i], scratch slots g.tbase1[j] + i) in one launch; n2 / n1 are
 // filled in by the launcher.
 bool tick_groups_supported(int n);
+bool tick_pairs_supported(int n);  // map sizes with a tick-pair kernel (k_tick_pair_c; at 2048 k_tick_pair_c_split)
 int tick_group_pipe_blocks(int n, int slots);  // pass-2 blocks of the pipelined form (0: not available at this map size)
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s,
                              const LaunchTiming &lt = LaunchTiming{});

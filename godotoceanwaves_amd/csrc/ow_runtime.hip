@@ -49,6 +49,7 @@ constexpr double kHostG = 9.81;  // wave_generator.gd:5
 struct ow_context {
     int n = 0, cascades = 0, layers = 0, device = 0;
     float depth = 20.0f;
+    bool no_merge = false;  // OW_FLAG_NO_TICK_GROUPS: one launch per pass, always
     int kernel_mode = 0;  // 0 = by batch size, 1 = standard, 2 = layer-parallel, 3 = compact-intermediate kernels (OW_FLAG_KERNELS_*)
     int last_family = 0;  // kernel family of the most recent batch
     hipStream_t stream = nullptr;
@@ -73,6 +74,12 @@ struct ow_context {
     // THAT layer (the reference's schedule enqueues one cascade per call: the other layers keep the faulted batch's bytes).
     uint32_t maps_faulted = 0, enqueued_since_sync = 0;
     uint32_t readback_faulted = 0;
+    ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
+    bool pc_valid[OW_MAX_CASCADES] = {};
+    // A lone tick (ow_update_all / ow_process callers: no look-ahead across ticks) of a compact-family batch in THREE launches instead of
+    // two: [pass 1 of half A] [pass 2 of A + pass 1 of half B: k_tick_pair_c] [pass 2 of B] -- independent work inside one tick shares a
+    // launch (0: off).  OW_DEBUG_SPLIT_TICK, read once by ow_create.
+    int split_lone_ticks = 0;
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
@@ -143,7 +150,7 @@ constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const size_t pair_texels = c->pair_texels, pl = (size_t)c->n * c->n;
-    if (count < 1 || !ow::tick_groups_supported(c->n)) return 0;
+    if (count < 1 || !ow::tick_pairs_supported(c->n)) return 0;
     // Where two full-size batches of intermediate next to the spectra do not fit the Infinity Cache (1024^2 x 8: 96 + 2 x 80 MiB), batches
     // of half the size do (96 + 2 x 40): every launch is then one full round of blocks (256 of each pass at 1024^2) instead of two --
     // measured (round 3, same process, us per tick, one launch per pass | pairs of 2-cascade batches): 1024^2 x 8 115.1 | 113.3; the full-size
@@ -159,7 +166,8 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
         if (!family_ok) return 0;  // (smaller batches would leave the compact family as well)
         // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
         const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
-        if (B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
+        // (2048^2: one cascade per batch is the only shape k_tick_pair_c_split has, and nothing but the intermediate is resident there anyway)
+        if (c->n <= 1024 && B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
         return B;
     }
     return 0;
@@ -175,10 +183,12 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
     // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
+    c->split_lone_ticks = 0;
+    if (const char *e = getenv("OW_DEBUG_SPLIT_TICK")) c->split_lone_ticks = atoi(e);
     c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
-    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_groups_supported(c->n)) return;
+    if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_pairs_supported(c->n)) return;
     for (int count = 1; count <= c->cascades; ++count) {
         int sizes[OW_MAX_CASCADES];
         if (pair_batches(c, count, sizes) > 0) c->pair_slots = std::max(c->pair_slots, sizes[0]);
@@ -348,6 +358,30 @@ ow_status validate_records(const ow_cascade_params *params, int count, double de
 }  // namespace ow
 namespace {
 
+uint32_t f32_word(float v) {
+    uint32_t w;
+    std::memcpy(&w, &v, 4);
+    return w;
+}
+// render_context.gd:122-135 for the modulate and unpack blocks of one cascade (wave_generator.gd:73,85)
+void record_frame_constants(ow_context *c, int cascade, const ow_cascade_params &p) {
+    ow_push_constants &w = c->pc_words[cascade];
+    std::memset(w.modulate, 0, sizeof(w.modulate));
+    std::memset(w.unpack, 0, sizeof(w.unpack));
+    w.modulate[0] = f32_word(p.tile_length[0]);
+    w.modulate[1] = f32_word(p.tile_length[1]);
+    w.modulate[2] = f32_word(c->depth);
+    w.modulate[3] = f32_word((float)p.time);
+    w.modulate[4] = (uint32_t)cascade;
+    w.unpack[0] = (uint32_t)cascade;
+    w.unpack[1] = f32_word((float)p.whitecap);
+    w.unpack[2] = f32_word((float)p.foam_grow_rate);
+    w.unpack[3] = f32_word((float)p.foam_decay_rate);
+    c->pc_valid[cascade] = true;
+}
+
+bool flags_no_merge(const ow_context *c) { return c->no_merge; }
+
 // _update() for a batch of cascade indices (wave_generator.gd:65-85)
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
@@ -382,7 +416,13 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
             pc.spread = (float)p.spread;
             OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
             p.should_generate_spectrum = 0;
+            uint32_t *w = c->pc_words[idx[i]].spectrum;  // wave_generator.gd:71, in the reference's order
+            std::memset(w, 0, sizeof(c->pc_words[idx[i]].spectrum));
+            w[0] = (uint32_t)pc.seed_x, w[1] = (uint32_t)pc.seed_y, w[2] = f32_word(pc.tile_x), w[3] = f32_word(pc.tile_y);
+            w[4] = f32_word(pc.alpha), w[5] = f32_word(pc.peak_frequency), w[6] = f32_word(pc.wind_speed), w[7] = f32_word(pc.angle);
+            w[8] = f32_word(pc.depth), w[9] = f32_word(pc.swell), w[10] = f32_word(pc.detail), w[11] = f32_word(pc.spread), w[12] = (uint32_t)idx[i];
         }
+        record_frame_constants(c, idx[i], p);
         ow::CascadeFrame &cf = args.c[i];
         cf.tile_x = p.tile_length[0];
         cf.tile_y = p.tile_length[1];
@@ -411,6 +451,28 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         if (c->timing) {
             ow_status st = next_events(c, &ev);
             if (st != OW_OK) return st;
+        }
+        if (c->split_lone_ticks > 0 && (c->split_lone_ticks % 10) != 0 && !c->timing && part.c[0].fault == 0 && nb >= 2 && c->last_family == 3 && ow::tick_groups_supported(c->n) &&
+            !(flags_no_merge(c))) {
+            // three launches, same item bodies (bit-identical): A = the first a launch slots, B = the rest; scratch slot = launch slot
+            const int a = (c->split_lone_ticks % 10) == 2 ? 1 : (nb + 1) / 2;
+            ow::TickGroupArgs ga;
+            std::memset(&ga, 0, sizeof(ga));
+            ga.pair_compact = 1;
+            for (int i = 0; i < nb; ++i) ga.time1[0][i] = part.c[i].time;
+            const int first[4] = {0, a, nb}, stages = 3;
+            for (int st = 0; st < stages; ++st) {  // stage st: pass 2 of piece st - 1, pass 1 of piece st
+                ga.slots2 = st >= 1 ? first[st] - first[st - 1] : 0;
+                ga.first2 = st >= 1 ? first[st - 1] : 0;
+                ga.tbase2[0] = ga.first2;
+                ga.slots1 = st < 2 ? first[st + 1] - first[st] : 0;
+                ga.first1 = st < 2 ? first[st] : 0;
+                ga.tbase1[0] = ga.first1;
+                ga.d2 = ga.slots2 > 0;
+                ga.d1 = ga.slots1 > 0;
+                OW_HIP(ow::launch_tick_group(c->n, part, ga, c->buf, c->stream, ow::LaunchTiming{}));
+            }
+            continue;
         }
         const ow::LaunchTiming t1{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}, t2{ev ? ev[2] : nullptr, ev ? ev[3] : nullptr};
         OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t1));  // modulate + rows + transpose (:73-80)
@@ -515,6 +577,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
+    c->no_merge = (cfg->flags & OW_FLAG_NO_TICK_GROUPS) != 0;
     plan_tick_groups(c, cfg->flags);
     if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
@@ -679,6 +742,7 @@ namespace {
 // returns 0 = not usable, the ticks per launch (group_depth) for the tick groups, -1 for the compact family's tick pairs
 int tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
     if (c->timing == 1 || c->inject_fault || c->pass_num_cascades_remaining != 0) return 0;
+    if (c->split_lone_ticks < 0 || c->split_lone_ticks >= 10) return 0;  // measurement: ow_run as a loop of lone ticks (10 + mode: split as mode; -1: two launches)
     int sizes[OW_MAX_CASCADES];
     const bool groups = ow::kernel_family(c->n, count, c->kernel_mode) == 4 && count <= c->group_max_count;
     const bool pairs = !groups && c->pair_slots > 0 && pair_batches(c, count, sizes) > 0;
@@ -731,6 +795,7 @@ void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_para
     for (int i = 0; i < count; ++i) {
         c->pass_parameters[i] = params[i];
         args.c[i].time = (float)params[count - 1 - i].time;
+        record_frame_constants(c, i, params[i]);  // (of the run's last tick)
     }
     c->pass_count = count;
     c->pass_num_cascades_remaining = 0;
@@ -1156,6 +1221,15 @@ ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omeg
                 o[3] = -m.y;
             }
     }
+    return OW_OK;
+}
+
+ow_status ow_get_push_constants(const ow_context *c, int32_t cascade, ow_push_constants *out) {
+    ow_status st = check_cascade(c, cascade);
+    if (st != OW_OK) return st;
+    if (!out) return fail(OW_ERR_INVALID, "null output");
+    if (cascade >= OW_MAX_CASCADES || !c->pc_valid[cascade]) return fail(OW_ERR_STATE, "cascade %d has not been launched yet", cascade);
+    *out = c->pc_words[cascade];
     return OW_OK;
 }
 

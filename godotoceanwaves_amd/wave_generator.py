@@ -254,6 +254,12 @@ class WaveGenerator:
         _lib.check(self._lib.ow_sample_surface(self.context, xz.ctypes.data, len(xz), sc.ctypes.data, len(sc), out.ctypes.data))
         return out
 
+    def get_push_constants(self, cascade):
+        """(spectrum[16], modulate[8], unpack[4]) uint32 words: the reference's push-constant blocks of this cascade's most recent launch"""
+        pc = _lib.ow_push_constants()
+        _lib.check(self._lib.ow_get_push_constants(self.context, cascade, C.byref(pc)))
+        return (np.array(pc.spectrum, np.uint32), np.array(pc.modulate, np.uint32), np.array(pc.unpack, np.uint32))
+
     def get_maps_f32(self, cascade):
         out = np.empty((self.map_size, self.map_size, 8), np.float32)
         _lib.check(self._lib.ow_get_maps_f32(self.context, cascade, out.ctypes.data))

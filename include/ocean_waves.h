@@ -350,6 +350,24 @@ ow_status ow_get_spectrum(ow_context *ctx, int32_t cascade, float *h0, float *om
  * shared by all batches: only cascades of the most recent pair of launches can be read (OW_ERR_STATE otherwise). */
 ow_status ow_get_intermediate(ow_context *ctx, int32_t cascade, float *out);
 
+/* The three push-constant blocks the reference packs for one _update of `cascade` (wave_generator.gd:71,73,85 through
+ * RenderingContext.create_push_constant, render_context.gd:122-135: ints as s32, floats narrowed to f32, zero padding up to a
+ * multiple of 16 bytes), as 32-bit words in the reference's own layouts, with the values this context's most recent launch for that
+ * cascade was given.  This is where FP64 parameters become FP32: the parity tests hold these words bit for bit to the packing
+ * restated from the reference.
+ *   spectrum (spectrum_compute.glsl:18-30, 52 -> 64 bytes): seed.x, seed.y, tile_length.x, tile_length.y, alpha, peak_frequency,
+ *            wind_speed, angle (rad), depth, swell, detail, spread, cascade_index -- of the most recent spectrum generation of this
+ *            cascade (all zero before the first)
+ *   modulate (spectrum_modulate.glsl:24-29, 20 -> 32 bytes): tile_length.x, tile_length.y, depth, time, cascade_index
+ *   unpack   (fft_unpack.glsl:20-25, 16 bytes): cascade_index, whitecap, foam_grow_rate, foam_decay_rate
+ * OW_ERR_STATE before the cascade's first launch. */
+typedef struct ow_push_constants {
+    uint32_t spectrum[16];
+    uint32_t modulate[8];
+    uint32_t unpack[4];
+} ow_push_constants;
+ow_status ow_get_push_constants(const ow_context *ctx, int32_t cascade, ow_push_constants *out);
+
 /* ---- host math: static funcs of WaveGenerator (wave_generator.gd:116-121), FP64 ---------------------- */
 double ow_jonswap_alpha(double wind_speed, double fetch_length_m);
 double ow_jonswap_peak_angular_frequency(double wind_speed, double fetch_length_m);

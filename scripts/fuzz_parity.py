@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzz of the HIP path against the oracle: random parameter records over the reference's exported ranges
-(wave_cascade_parameters.gd:7-35; wind / fetch also at their clamped minima), random seeds, sizes 128 .. 1024, random batch shapes and
+(wave_cascade_parameters.gd:7-35; wind / fetch also at their clamped minima; FP64 values, not rounded to FP32), random seeds, sizes 128 .. 2048, random batch shapes and
 schedules (update_all / run / the reference's update + one cascade per frame), random deltas and start times.
-   python scripts/fuzz_parity.py [cases [seed]] [--small] [--wilder]    one line per case; exit 1 on the first failure (prints the records)
---small: sizes up to 512 (the oracle's CPU time is what a case costs); --wilder: any tile aspect and start times up to 5000 s -- at aspects
+   python scripts/fuzz_parity.py [cases [seed]] [--small] [--wilder] [--big]    one line per case; exit 1 on the first failure (prints the records)
+--big: 1024 and 2048 only (the split-plan pass 1, k_pass1c_split, is reached at 2048 alone); --small: sizes up to 512 (the oracle's CPU time is what a case costs); --wilder: any tile aspect and start times up to 5000 s -- at aspects
 of 16 : 1 and more, hours into a session, the worst FP32 channel error seen was 3.5e-5 (typical: 5e-6; tolerance 1e-4): a small channel
 inherits the absolute rounding error of the large one it shares a packed transform with (spectrum_modulate.glsl:84-89), in the
 reference's own arithmetic just as here.  tests/test_fuzz_parity.py freezes a few cases."""
@@ -16,19 +16,21 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 
-f32r = lambda v: float(np.float32(v))
+f32r = lambda v: float(np.float32(v))   # tile_length only: a Vector2's components are FP32 in Godot
 
 
 def draw_case(rng, sizes=(128, 256, 256, 256, 512, 512, 512, 1024), wilder=False):
+    """Scalars are drawn as FP64 and stay FP64 (a GDScript float; wave_generator.gd:69-70 evaluates alpha / omega_p from them un-narrowed):
+    both sides -- the C-ABI record (ABI 4) and the oracle's -- get the very same doubles."""
     n = int(rng.choice(sizes))
-    c = int(rng.integers(1, 5 if n >= 1024 else 9))
+    c = int(rng.integers(1, 3 if n >= 2048 else 5 if n >= 1024 else 9))
     recs = []
     for _ in range(c):
         tx = f32r(rng.uniform(4, 400))
         tile = (tx, f32r(rng.uniform(4, 400) if wilder else tx * rng.uniform(0.25, 4.0))) if rng.random() < 0.4 else (tx, tx)
-        recs.append(dict(tile_length=tile, wind_speed=f32r(rng.uniform(0.5, 60) if rng.random() < 0.9 else 1e-4), wind_direction=f32r(rng.uniform(-400, 400)),
-                         fetch_length=f32r(rng.uniform(1, 3000) if rng.random() < 0.9 else 1e-4), swell=f32r(rng.uniform(0, 2)), spread=f32r(rng.uniform(0, 1)),
-                         detail=f32r(rng.uniform(0, 1)), whitecap=f32r(rng.uniform(0, 2)), foam_amount=f32r(rng.uniform(0, 10)),
+        recs.append(dict(tile_length=tile, wind_speed=float(rng.uniform(0.5, 60) if rng.random() < 0.9 else 1e-4), wind_direction=float(rng.uniform(-400, 400)),
+                         fetch_length=float(rng.uniform(1, 3000) if rng.random() < 0.9 else 1e-4), swell=float(rng.uniform(0, 2)), spread=float(rng.uniform(0, 1)),
+                         detail=float(rng.uniform(0, 1)), whitecap=float(rng.uniform(0, 2)), foam_amount=float(rng.uniform(0, 10)),
                          spectrum_seed=(int(rng.integers(-10000, 10001)), int(rng.integers(-10000, 10001))),
                          time=float(rng.uniform(0, 5000 if wilder else 2000))))
     delta = float(rng.choice([1 / 50, 1 / 144, 0.1, float(rng.uniform(1e-3, 0.2))]))
@@ -95,7 +97,9 @@ if __name__ == "__main__":
     pos = [a for a in sys.argv[1:] if not a.startswith("-")]
     cases, seed = (int(pos[0]) if pos else 40), (int(pos[1]) if len(pos) > 1 else 7)
     rng = np.random.default_rng(seed)
-    sizes = (128, 256, 256, 256, 512, 512, 512) + (() if "--small" in sys.argv else (1024,))
+    sizes = (128, 256, 256, 256, 512, 512, 512) + (() if "--small" in sys.argv else (1024, 2048))
+    if "--big" in sys.argv:
+        sizes = (1024, 2048, 2048)
     worst_all = 0.0
     for k in range(cases):
         case = draw_case(rng, sizes, "--wilder" in sys.argv)

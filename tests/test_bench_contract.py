@@ -26,7 +26,7 @@ def test_bench_needs_a_gpu_and_says_so():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags,kernel", [((), "k_tick_pair_c"), (("--map-size", "256"), "k_tick_group_c_lp"), (("--map-size", "2048", "--cascades", "1"), "k_pass")])
+@pytest.mark.parametrize("flags,kernel", [((), "k_tick_pair_c"), (("--map-size", "256"), "k_tick_group_c_lp"), (("--map-size", "2048", "--cascades", "1"), "k_tick_pair_c_split")])
 def test_one_json_line_with_the_contract_keys(flags, kernel):
     r = run_bench("--steps", "40", "--warmup", "5", "--min-time", "0.05", "--cpu-seconds", "1", *flags)
     assert r.returncode == 0, r.stderr[-2000:]

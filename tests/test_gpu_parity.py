@@ -208,6 +208,39 @@ def test_many_cascades_and_batched_launches_match_oracle(n, ids, kernels):
             assert gen.get_intermediate(len(ids) - 1).shape == (4, n, n, 2)   # one batch: every cascade's intermediate is there
 
 
+@pytest.mark.parametrize("n,count", [(2048, 4), (2048, 8), (1024, 8)], ids=["C5_2048x4", "2048x8", "C4_total_1024x8"])
+def test_baseline_configs_through_ow_run_match_the_oracle(n, count):
+    """The exact BASELINE configurations beyond the headline -- C5 = 2048^2 x 4 (LDS-tiling stress), 2048^2 x 8, and 1024^2 x 8 (C4's
+    per-node total) -- through ow_run, the call bench.py times: one ordinary tick, then the merged launches where a size has them (tick
+    pairs).  Every FP32 channel <= 1e-4 of the oracle (max-norm relative), the RGBA16F maps within one FP16 ulp (+ 1e-5 of the channel
+    maximum) of the oracle's and exactly the RTE quantisation of the FP32 channels, foam within one FP16 step; three ticks."""
+    ids = list(range(count))
+    gen, params = make_gen(n, ids)
+    og = H.oracle_generator(n, ids)
+    gen.run(UPDATE_DELTA, params, 3)
+    for _ in range(3):
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.last_kernel_family() in ("compact", "tick_pairs_compact")
+    worst = 0.0
+    for i in range(count):
+        assert params[i].time == og.params[i].time
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                e = H.relmax(f32[..., c], ref[..., c])
+                worst = max(worst, e)
+                assert e < H.TOL_F32, (i, name, e)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
+        assert H.fp16_close(disp, og.displacement(i)) <= 1.0, i
+        assert H.fp16_close(norm[..., :3], og.normal(i)[..., :3]) <= 1.0, i
+        assert np.abs(norm[..., 3].astype(np.float64) - og.normal(i)[..., 3].view(np.float16).astype(np.float64)).max() <= H.TOL_FOAM_ABS
+    print(f"{n}^2 x {count} through ow_run: worst FP32 channel error {worst:.2e}")
+
+
 def _edge_cases():
     from edge_presets import edge_presets
     return sorted(edge_presets().items())

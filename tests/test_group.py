@@ -246,3 +246,44 @@ def test_resharding_through_the_checkpoint_state():
         assert np.array_equal(bits(got[c][0]), bits(want[c][0])) and np.array_equal(bits(got[c][1]), bits(want[c][1])), c
     assert [p.time for p in pa] == [p.time for p in pr]
     b.free()
+
+
+def test_a_faulted_shard_keeps_its_gathered_layers_refused_until_a_clean_gather():
+    """ow_group_gather_wait reports a shard's device-side failure ONCE -- but the garbage it copied stays in the gathered arrays, so the
+    group's readers (ow_group_get_maps of that shard's layers, ow_group_sample_surface over them) keep refusing until a later gather of
+    that shard has landed cleanly; the other shard's layers are handed out all along; every pending shard is waited for."""
+    n, shards, per = 2048, 2, 1
+    grp = WaveGeneratorGroup()
+    grp.map_size, grp.force_peer_path = n, True
+    grp.init_gpu([0] * shards, per)
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in range(shards * per)]
+    grp.update_all(UPDATE_DELTA, params)
+    grp.gather_begin()
+    grp.gather_wait()
+    grp.get_maps(0), grp.get_maps(1)
+    grp.shard(1).debug_inject_fault(1)                 # shard 1's next batch: a wave-pair rendezvous gives up (2048^2 kernels)
+    grp.update_all(UPDATE_DELTA, params)
+    grp.gather_begin()
+    with pytest.raises(_lib.OceanWavesError) as e:
+        grp.gather_wait()
+    assert e.value.status == _lib.OW_ERR_HIP and "shard 1" in str(e.value)
+    with pytest.raises(_lib.OceanWavesError) as e:
+        grp.gather_wait()                              # nothing is left pending: every shard was waited for
+    assert e.value.status == _lib.OW_ERR_STATE
+    clean, _ = lone(n, [0], 2, run=False)
+    d0, m0 = grp.get_maps(0)                           # shard 0's layer: fine, and the right bytes
+    assert np.array_equal(bits(d0), bits(clean.get_maps(0)[0])) and np.array_equal(bits(m0), bits(clean.get_maps(0)[1]))
+    scales = [(1 / 88.0, 1 / 88.0, 1.0, 1.0), (1 / 57.0, 1 / 57.0, 1.0, 1.0)]
+    for _ in range(2):                                 # sticky: not consumed by the first refusal
+        with pytest.raises(_lib.OceanWavesError) as e:
+            grp.get_maps(1)
+        assert e.value.status == _lib.OW_ERR_HIP
+        with pytest.raises(_lib.OceanWavesError):
+            grp.sample_surface([[3.0, 4.0]], scales)
+    grp.sample_surface([[3.0, 4.0]], scales[:1])       # sums over layer 0 only: allowed
+    grp.update_all(UPDATE_DELTA, params)               # the shard recomputes its layer ...
+    grp.gather_begin()
+    grp.gather_wait()                                  # ... and a gather of it lands cleanly: handed out again
+    grp.get_maps(1)
+    grp.sample_surface([[3.0, 4.0]], scales)
+    grp.free()

@@ -201,3 +201,35 @@ def test_a_rendezvous_that_gives_up_is_an_error_not_maps():
             assert np.abs(f32[..., c] - want[..., c]).max() <= H.TOL_FOAM_ABS
         else:
             assert H.relmax(f32[..., c], want[..., c]) < H.TOL_F32, name
+
+
+def test_a_faulted_layer_stays_refused_until_that_layer_is_recomputed():
+    """The reference's schedule enqueues ONE cascade per call (wave_generator.gd:56-63).  After a faulted batch of two cascades, an
+    ow_process that recomputes cascade 1 lifts the mark of layer 1 only: layer 0 still holds the faulted batch's bytes and stays
+    refused (ow_get_maps, ow_sample_surface over it) until its own cascade has been processed again."""
+    n, ids = 2048, [1, 2]
+    gen, L = raw_gen(n, 2)
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+    gen.update_all(UPDATE_DELTA, params)
+    gen.sync()
+    gen.debug_inject_fault(1)
+    gen.update_all(UPDATE_DELTA, params)       # both layers recomputed by launches that report a failure
+    with pytest.raises(_lib.OceanWavesError):
+        gen.sync()
+    for layer in (0, 1):
+        with pytest.raises(_lib.OceanWavesError):
+            gen.get_maps(layer)
+    gen.update(UPDATE_DELTA, params)
+    gen._process(0.0)                          # highest index first: cascade 1 only
+    gen.sync()
+    gen.get_maps(1)                            # recomputed: handed out again
+    with pytest.raises(_lib.OceanWavesError) as e:
+        gen.get_maps(0)                        # not recomputed: still the faulted batch's bytes
+    assert e.value.status == _lib.OW_ERR_HIP
+    scales = [(1 / 57.0, 1 / 57.0, 1.0, 1.0), (1 / 16.0, 1 / 16.0, 1.0, 1.0)]
+    with pytest.raises(_lib.OceanWavesError):
+        gen.sample_surface([[1.0, 2.0]], scales)    # the consumer's sums run over layer 0 as well
+    gen._process(0.0)                          # cascade 0
+    gen.sync()
+    gen.get_maps(0)
+    gen.sample_surface([[1.0, 2.0]], scales)

@@ -1,4 +1,4 @@
-"""ow_run on the compact family (map sizes up to 1024^2; up to eight 1024^2 cascades) goes out in TICK PAIRS (k_tick_pair_c: pass 2 of one batch of at most 4 Mi texels and
+"""ow_run on the compact family goes out in TICK PAIRS (k_tick_pair_c, at 2048^2 k_tick_pair_c_split: pass 2 of one batch of at most 4 Mi texels and
 pass 1 of the next batch of the run in one launch, the compact family's own item bodies) -- held to one launch per pass BITWISE below, too.
 ow_run on a small batch: from the second tick on, pass 2 of tick k and pass 1 of tick k + 1 go out in ONE launch (k_tick_group_c_lp;
 the two are independent, the scratch intermediate is double-buffered by tick parity) -- against the same ticks as one pair of
@@ -64,7 +64,10 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, forms, monke
 
 @pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7]),
                                    (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]),  # two batches per tick: 3 + 2, 4 + 3
-                                   (1024, [0, 1, 2, 3, 4, 5, 6, 7])])  # four batches of two (two of four would not fit the Infinity Cache next to the spectra)
+                                   (1024, [0, 1, 2, 3, 4, 5, 6, 7]),  # four batches of two (two of four would not fit the Infinity Cache next to the spectra)
+                                   # 2048^2 (k_tick_pair_c_split, round 4): one cascade per batch; pass 2's 16-wave blocks beside pass-1 blocks that
+                                   # hold the two 4-row split-plan items of an 8-row unit, each with its own LDS arrival counter as its barrier
+                                   (2048, [1]), (2048, [0, 2]), (2048, [0, 1, 2, 3])])
 @pytest.mark.parametrize("frames", [2, 3, 4, 9])
 def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
     a, pa = make(n, ids, True)
@@ -163,11 +166,11 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
     a.sync(); b.sync()
     assert a.last_kernel_family() == "tick_groups_compact"
     same_maps(a, b, len(ids))
-    for n_big, ids_big in ((2048, [0]), (2048, [0, 1, 2])):  # 2048^2: no merged launches (the two passes want blocks of different sizes)
+    for n_big, ids_big in ((2048, [0]), (2048, [0, 1, 2])):  # 2048^2: tick pairs of one cascade per batch (k_tick_pair_c_split), never tick groups
         big, pbig = make(n_big, ids_big, True)
         big.run(UPDATE_DELTA, pbig, 4)
         big.sync()
-        assert big.last_kernel_family() == "compact"
+        assert big.last_kernel_family() == "tick_pairs_compact" and big.last_batch_cascades() == 1 and big.tick_group_depth() == 1
         big.free()
     # 1024^2 x 8: two full batches of intermediate do not fit the Infinity Cache next to the spectra -- the run goes out in pairs of
     # half-size batches (four batches of two per tick) instead of falling back to one launch per pass
