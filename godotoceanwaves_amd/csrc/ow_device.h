@@ -227,24 +227,56 @@ struct Dft<16> {
 //   stage output layout: d[b*R + dft_pos(k)] <-> element q + s*(R*p + k)    (times W_n^{p*k} unless last stage)
 //   after the last stage: element index = t + T*b + (N/R)*k  (natural order, lanes contiguous)
 // ------------------------------------------------------------------------------------
-template <int N, int J>
+// exp(+2 pi i m / 32) for compile-time m in [0, 16] (the ordinal part of W_N^k; the lane part comes from a table)
+constexpr float kRootCos32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                                 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
+constexpr float root32_cos(int i) { return i <= 8 ? kRootCos32[i] : -kRootCos32[16 - i]; }
+constexpr float root32_sin(int i) { return i <= 8 ? kRootCos32[8 - i] : kRootCos32[i - 8]; }
+// HALF TABLE (TWH, rows that span two waves: N = 2048).  The stage-0 block of the table is [15][N/16] = 15 K complex at N = 2048, and with
+// it an 8-wave block of pass 2 (4 columns) needs 86 KB of LDS: two of them do not fit a CU.  But lane t >= 64 -- the row's second wave --
+// needs exp(2 pi i t k / N) = exp(2 pi i (t - 64) k / N) * exp(2 pi i k / 32): the first wave's entry times a compile-time 32nd root of
+// unity.  So the table keeps the first 64 columns only ([15][64], then the stage-1 block unchanged: plan_twh_total), 8.6 KB, and the second
+// wave of a row pays fifteen constant rotations per transform (wave-uniform branch).  78 KB per block: two blocks per CU, of either pass.
+constexpr int kTwhCols = 64;
+constexpr int plan_twh_off(int N, int j) { return j == 0 ? 0 : (plan_R(N, 0) - 1) * kTwhCols; }
+constexpr int plan_twh_total(int N) { return plan_twh_off(N, 1) + plan_tw_size(N, 1); }
+template <int N, int J, bool TWH = false>
 OW_DEV void fft_stage_compute(cplx *d, int t, const cplx *__restrict__ tw) {
     constexpr int R = plan_R(N, J), B = plan_B(N, J), T = plan_T(N), s = plan_s(N, J), m = plan_m(N, J);
     constexpr bool last = (J == plan_S(N) - 1);
+    static_assert(!TWH || (plan_S(N) == 3 && plan_B(N, 0) == 1 && plan_T(N) == 2 * kTwhCols), "half table: a row of exactly two waves");
 #pragma unroll
     for (int b = 0; b < B; ++b) Dft<R>::run(d + b * R);
     if (!last) {
         // twiddles are fetched (LDS table) only now, when the butterfly's temporaries are dead
         OW_SCHED_FENCE();
-        constexpr int off = plan_tw_off(N, J);
+        constexpr int off = TWH ? plan_twh_off(N, J) : plan_tw_off(N, J);
         const cplx *twj = tw + off;
+        if constexpr (TWH && J == 0) {
+#if OW_DEVICE_BUILD
+            const bool upper = __builtin_amdgcn_readfirstlane(t) >= kTwhCols;  // the row's second wave (wave-uniform)
+#else
+            const bool upper = t >= kTwhCols;
+#endif
+            const int p = t & (kTwhCols - 1);
+            if (upper) {
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const int p = (t + T * b) / s;
+                for (int k = 1; k < R; ++k) d[dft_pos(R, k)] = cmul_const(d[dft_pos(R, k)], root32_cos(k), root32_sin(k));
+            }
 #pragma unroll
             for (int k = 1; k < R; ++k) {
-                d[b * R + dft_pos(R, k)] = cmul(d[b * R + dft_pos(R, k)], lds_read(twj + (k - 1) * m + p));
-                if (k % 5 == 0) OW_SCHED_FENCE();  // a few table reads in flight at a time, not all 15
+                d[dft_pos(R, k)] = cmul(d[dft_pos(R, k)], lds_read(twj + (k - 1) * kTwhCols + p));
+                if (k % 5 == 0) OW_SCHED_FENCE();
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int p = (t + T * b) / s;
+#pragma unroll
+                for (int k = 1; k < R; ++k) {
+                    d[b * R + dft_pos(R, k)] = cmul(d[b * R + dft_pos(R, k)], lds_read(twj + (k - 1) * m + p));
+                    if (k % 5 == 0) OW_SCHED_FENCE();  // a few table reads in flight at a time, not all 15
+                }
             }
         }
         OW_SCHED_FENCE();
@@ -398,11 +430,6 @@ struct OutMap {
 // instead of four -- is no faster: 33.7 against 32.3 us at 2048^2 x 1, 34.9 against 35.2 at x 4.)
 // ------------------------------------------------------------------------------------
 constexpr bool plan_split(int N) { return N == 2048; }
-// exp(+2 pi i m / 32) for compile-time m in [0, 16] (the ordinal part of W_N^k; the lane part comes from a table)
-constexpr float kRootCos32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
-                                 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
-constexpr float root32_cos(int i) { return i <= 8 ? kRootCos32[i] : -kRootCos32[16 - i]; }
-constexpr float root32_sin(int i) { return i <= 8 ? kRootCos32[8 - i] : kRootCos32[i - 8]; }
 
 // ------------------------------------------------------------------------------------
 // Accurate sin/cos of an FP32 phase up to ~2.5e4 rad (never the hardware approximations: SURVEY.md H1).

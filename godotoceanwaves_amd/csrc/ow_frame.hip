@@ -106,11 +106,17 @@ template <int N, bool F32>
 static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
         return hipErrorInvalidValue;
+    if constexpr (plan_split(N)) {  // 8-wave blocks of both kinds: 4 columns (pass 2), 4 rows (pass 1)
+        g.n2 = g.slots2 * (N / PairSplitGeo<N>::kCols);
+        g.n1 = g.slots1 * (N / 4);
+        if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
+        launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, args, g, (Stamp *)nullptr);
+        return hipGetLastError();
+    }
     g.n2 = g.slots2 * (N / kWgRows);
     g.n1 = g.slots1 * (N / kWgRows);
     if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-    if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
-    else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+    if constexpr (!plan_split(N)) launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
     return hipGetLastError();
 }
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----

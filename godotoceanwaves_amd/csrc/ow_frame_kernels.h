@@ -205,19 +205,42 @@ __device__ __forceinline__ void tw_commit(const TwPrefetch<N> &p, cplx *tw_lds) 
     lds_barrier();
 }
 
+// the same for a table of COUNT entries and a block of THREADS threads (the half table of the 2048^2 pass 2 in 16- and 8-wave blocks)
+template <int COUNT, int THREADS>
+struct TablePrefetch {
+    static constexpr int K = (COUNT + THREADS - 1) / THREADS;
+    cplx v[K];
+    __device__ __forceinline__ void fetch(const cplx *__restrict__ table) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = (int)threadIdx.x + k * THREADS;
+            v[k] = table[i < COUNT ? i : 0];
+        }
+    }
+    __device__ __forceinline__ void commit(cplx *table_lds) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = (int)threadIdx.x + k * THREADS;
+            if (i < COUNT) table_lds[i] = v[k];
+        }
+        lds_barrier();
+    }
+};
+
 // row IFFT of the 16 points in d[] (lane t of the row), exchanging through this row's LDS buffer
 // (BLOCK_GATE: a workgroup barrier right before the first write into the row regions -- pass 1 uses it when
 // other waves may still be draining the previous layer's staged rows out of them)
 // (gate(): called right before the first write into the row regions)
-template <int N, class Gate>
+// (TWH: tw is the half table of ow_device.h "HALF TABLE")
+template <int N, bool TWH = false, class Gate>
 __device__ __forceinline__ void row_ifft_gated(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RowSync<N> &rs, Gate gate) {
-    fft_stage_compute<N, 0>(d, t, tw);
+    fft_stage_compute<N, 0, TWH>(d, t, tw);
     gate();
     fft_stage_write<N, 0>(d, t, lds_row);
     rs.sync();
     fft_stage_read<N, 1>(d, t, lds_row);
     rs.sync();
-    fft_stage_compute<N, 1>(d, t, tw);
+    fft_stage_compute<N, 1, TWH>(d, t, tw);
     if constexpr (plan_S(N) == 3) {
         if constexpr (plan_lane_exchange(N)) {
             fft_lane_exchange<N>(d);  // row-swap instructions, no LDS
@@ -230,9 +253,9 @@ __device__ __forceinline__ void row_ifft_gated(cplx *d, int t, cplx *lds_row, co
         fft_stage_compute<N, 2>(d, t, tw);
     }
 }
-template <int N, bool BLOCK_GATE = false>
+template <int N, bool BLOCK_GATE = false, bool TWH = false>
 __device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RowSync<N> &rs) {
-    row_ifft_gated<N>(d, t, lds_row, tw, rs, [] {
+    row_ifft_gated<N, TWH>(d, t, lds_row, tw, rs, [] {
         if constexpr (BLOCK_GATE) lds_barrier();
     });
 }
@@ -639,10 +662,17 @@ __global__ __launch_bounds__(plan_wg_threads(N), OW_P1_WAVES) void k_pass1c(Devi
 // a function of the lane index tau inside the item: shared by k_pass2c and the compact tick-group kernel (k_tick_group_c, where a
 // block walks through several ticks of its columns).  foam_pk: the lane's 16 FP16 foam values; foam_io & 1: load them from the
 // foam plane first, & 2: store them back at the end (the group kernel carries them in registers from tick to tick).
+// At N = 2048 (rows of two waves) tw_lds is the HALF table (p2c_table_total(N) entries from p2c_table(buf)): the row's second wave rotates
+// its stage-0 twiddles by a constant instead of reading its own half of a 16 KB table -- so that a 4-column block fits a CU twice.
+constexpr bool p2c_half_table(int N) { return plan_row_spans_waves(N); }
+constexpr int p2c_table_total(int N) { return p2c_half_table(N) ? plan_twh_total(N) : plan_tw_total(N); }
+template <int N>
+__device__ __forceinline__ const cplx *p2c_table(const DeviceBuffers &buf) { return p2c_half_table(N) ? buf.tw_half : buf.tw; }
 template <int N, bool F32, int AUX_T, int AUX_O, class Issued>
 __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds, cplx *rows_lds,
                                             RowSync<N> &rs, Issued issued, uint32_t (&foam_pk)[kP / 2], int foam_io = 3) {
     constexpr int Tn = plan_T(N), P = kP;
+    constexpr bool TWH = p2c_half_table(N);
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
     const uint32_t plane = (uint32_t)N * N;
     cplx *lds_row = rows_lds + rw * plan_region_cplx(N);
@@ -667,7 +697,7 @@ __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const Casc
         const cplx r2 = side_row(2);
         issued();
         Pass2<N>::put_row0(f2, t, r2);
-        row_ifft<N>(f2, opaque(t), lds_row, tw_lds, rs);
+        row_ifft<N, false, TWH>(f2, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         Pass2<N>::template after_f2<F32>(f2, hz_pk, c2, (uint32_t)(xp * N + opaque(t)), f32_c);
     }
@@ -679,7 +709,7 @@ __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const Casc
         Pass2<N>::template load_layer<AUX_T>(c0, tq, xp, 0, T_c);
 #pragma unroll
         for (int j = 0; j < P; ++j) f0[j] = c0[j];
-        row_ifft<N>(f0, opaque(t), lds_row, tw_lds, rs);
+        row_ifft<N, false, TWH>(f0, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         const int tr = opaque(t);
         Pass2<N>::template after_f0<F32, AUX_O>(f0, hz_pk, tr, xp, (uint32_t)(xp * N + tr), disp_c, f32_c);
@@ -691,7 +721,7 @@ __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const Casc
         const int tq = opaque(t);
         Pass2<N>::derive_dx(c0, tq, xp, dky, pcol_c);
         Pass2<N>::put_row0(c0, tq, side_row(1));
-        row_ifft<N>(c0, opaque(t), lds_row, tw_lds, rs);
+        row_ifft<N, false, TWH>(c0, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         Pass2<N>::template after_f1<F32>(c0, dhx_dx, gx_pk, (uint32_t)(xp * N + opaque(t)), f32_c);
     }
@@ -702,7 +732,7 @@ __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const Casc
         Pass2<N>::template load_layer<AUX_T>(f3, tq, xp, 2, T_c);
         Pass2<N>::put_row0(f3, tq, side_row(3));
         if (foam_io & 1) Pass2<N>::load_foam(foam_pk, tq, xp, foam_c);
-        row_ifft<N>(f3, opaque(t), lds_row, tw_lds, rs);
+        row_ifft<N, false, TWH>(f3, opaque(t), lds_row, tw_lds, rs);
         OW_SCHED_FENCE();
         const int tr = opaque(t);
         Pass2<N>::template after_f3<F32, AUX_O>(f3, dhx_dx, c2, gx_pk, foam_pk, (uint32_t)(xp * N + tr), cf, norm_c, f32_c);
@@ -714,11 +744,12 @@ template <int N, bool F32, int AUX_T = kAuxDefault, int AUX_O = kAuxDefault>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers buf, FrameArgs args) {
     constexpr int Tn = plan_T(N);
     static_assert(Tn >= 16, "Pass2::load_c1 needs N/16 to be a multiple of the 16-row line");
-    __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows)];
+    constexpr int TW = p2c_table_total(N), ROWS_CPLX = plan_region_cplx(N) * kWgRows;
+    __shared__ __attribute__((aligned(16))) cplx lds[TW + ROWS_CPLX + plan_sync_flag_cplx(N, kWgRows)];
     cplx *tw_lds = lds;
-    cplx *rows_lds = lds + plan_tw_total(N);
+    cplx *rows_lds = lds + TW;
     const int tau = threadIdx.x;
-    int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+    int *sync_flags = reinterpret_cast<int *>(lds + TW + ROWS_CPLX);
     RowSync<N> rs;
     rs.attach(sync_flags, tau / Tn, (tau / 64) & 1);
     rs.watch(buf.status, args.c[0].fault);
@@ -728,10 +759,10 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_pass2c(DeviceBuffers 
     p2_block_to_rows<N>(slot, row0);
     const CascadeFrame cf = args.c[slot];
     fetch_arguments(buf, cf);
-    TwPrefetch<N> twp;
-    tw_fetch<N>(twp, buf.tw);
+    TablePrefetch<TW, plan_wg_threads(N)> twp;
+    twp.fetch(p2c_table<N>(buf));
     uint32_t foam_pk[kP / 2];
-    pass2c_item<N, F32, AUX_T, AUX_O>(buf, cf, slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
+    pass2c_item<N, F32, AUX_T, AUX_O>(buf, cf, slot, row0, tau, tw_lds, rows_lds, rs, [&] { twp.commit(tw_lds); }, foam_pk);
 }
 
 // ===================================================================================================
@@ -764,8 +795,6 @@ template <class SG>
 struct SplitTw {
     cplx v[SG::kTwPerThread];
 };
-// (tau: the thread's index inside the item's SG::kThreads lanes; the barrier behind the commit is BLOCK-wide -- where two items share a
-//  block and its table, k_tick_pair_c_split, both write the same values and meet at the same barrier)
 template <class SG>
 __device__ __forceinline__ void split_tw_fetch(SplitTw<SG> &p, const cplx *__restrict__ tw_split, int tau) {
 #pragma unroll
@@ -784,80 +813,18 @@ __device__ __forceinline__ void split_tw_commit(const SplitTw<SG> &p, cplx *tw_l
     lds_barrier();
 }
 
-// Barrier among the waves of ONE split-plan item.  Alone in its block (k_pass1c_split) that is the block's own LDS-only barrier.  Two items
-// side by side in one block (k_tick_pair_c_split: the block has pass 2's sixteen waves, an item eight) must NOT meet at s_barrier -- the
-// point of the 4-row items is that each runs load -> transform -> store at its own pace --, so each has an arrival counter in LDS: a wave
-// that has finished its LDS traffic adds one and polls until all W have (monotonic count, never reset).  The wait is bounded by wall time
-// and a give-up is reported through the status word, exactly as RowSync's.
-struct BlockBarrier {
-    __device__ __forceinline__ void sync() { lds_barrier(); }
-};
-template <int W>
-struct SubBlockBarrier {
-    typedef __attribute__((address_space(3))) int lds_int;
-    uint32_t addr = 0;  // byte offset of the arrival counter inside the block's LDS
-    int target = 0;
-    uint32_t *status = nullptr;
-    // ~0.1 s of polls (one poll = an LDS round trip + s_sleep 1, >= 0.1 us): three orders of magnitude beyond the kernel's duration, like
-    // RowSync's 20 ms of wall time a bound against a BUG, not against a slow neighbour
-    static constexpr uint32_t kPollLimit = 1u << 20;
-    __device__ __forceinline__ void attach(int *word, uint32_t *status_word) {
-        addr = (uint32_t)(uintptr_t)(lds_int *)word;
-        status = status_word;
-    }
-    // The whole barrier is ONE opaque instruction to the compiler -- wait for my LDS traffic, one lane adds 1, poll until all W waves have,
-    // report a give-up -- with no control flow at the C level: as C (an exec-masked atomic, a poll loop, a give-up branch) it cut the
-    // item body into basic blocks at every barrier and the register allocator, at 126 of 128 VGPRs, spilled thirty of them around each
-    // (k_tick_pair_c_split: 124 - 148 bytes of scratch per lane; none with s_barrier in the same place, none with this form).
-    __device__ __forceinline__ void sync() {
-        target += W;
-        uint32_t polls, seen, v, w;
-        uint64_t saved_exec;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\t"              // release: this wave's LDS reads / writes are done
-                     "v_mov_b32 %[v], %[addr]\n\t"
-                     "v_mov_b32 %[w], 1\n\t"
-                     "s_mov_b64 %[sx], exec\n\t"
-                     "s_mov_b64 exec, 1\n\t"
-                     "ds_add_u32 %[v], %[w]\n\t"
-                     "s_mov_b64 exec, %[sx]\n\t"
-                     "s_mov_b32 %[it], 0\n"
-                     "1:\n\t"
-                     "v_mov_b32 %[v], %[addr]\n\t"
-                     "ds_read_b32 %[v], %[v]\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "v_readfirstlane_b32 %[s], %[v]\n\t"
-                     "s_cmp_ge_i32 %[s], %[target]\n\t"
-                     "s_cbranch_scc1 3f\n\t"
-                     "s_sleep 1\n\t"
-                     "s_add_u32 %[it], %[it], 1\n\t"
-                     "s_cmp_lt_u32 %[it], %[limit]\n\t"
-                     "s_cbranch_scc1 1b\n\t"
-                     "v_mov_b32 %[v], 0\n\t"                 // gave up: say so in the status word (never silently), then go on
-                     "v_mov_b32 %[w], %[bit]\n\t"
-                     "global_store_dword %[v], %[w], %[status] sc0 sc1\n\t"
-                     "s_waitcnt vmcnt(0)\n"
-                     "3:\n"
-                     : [it] "=&s"(polls), [v] "=&v"(v), [w] "=&v"(w), [s] "=&s"(seen), [sx] "=&s"(saved_exec)
-                     : [addr] "s"(addr), [target] "s"(target), [limit] "s"(kPollLimit), [bit] "s"(kStatusRowSyncTimeout), [status] "s"(status)
-                     : "scc", "memory");
-    }
-};
-
 // one ITEM of the split-plan pass 1 = rows row0 .. row0 + ROWS - 1 of launch slot `tslot` (scratch) / cascade cf.cascade at time `time`, as a
-// function of the lane index tau (0 .. SG::kThreads - 1) inside the item.  tw_lds: the N/2-plan table (SG::TW complex; may be shared by the
-// items of a block); rows_lds: the item's 2 ROWS row regions (SG::R complex each); sync_flags: 2 ROWS ints, the item's own; bar: the barrier
-// among the item's waves (BlockBarrier where the item is the block).  stamp(k, keep): developer phase stamps (tools/kbench_2048pair).
-// LROWS / rbase: the row regions are laid out for LROWS rows ([E regions of rows 0 .. LROWS - 1][O regions]) and this item's rows are
-// rbase .. rbase + ROWS - 1 of them (LROWS = ROWS, rbase = 0 where the item has the regions to itself): a second item of the same block is
-// then an INDEX offset from the block's wave / lane numbers, not a dynamic base address under every LDS access.
-template <int N, int ROWS, int AUX_T, int AUX_H, int LROWS = ROWS, class Bar, class Stamper>
+// function of the lane index tau (0 .. SG::kThreads - 1); the item is the whole block (its barriers are the block's).  tw_lds: the N/2-plan
+// table (SG::TW complex); rows_lds: 2 ROWS row regions (SG::R complex each); sync_flags: 2 ROWS ints.  stamp(k, keep): developer phase stamps
+// (tools/kbench_2048pair).
+template <int N, int ROWS, int AUX_T, int AUX_H, class Stamper>
 __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int fault, cplx *tw_lds,
-                                                  cplx *rows_lds, int *sync_flags, int tau, Bar &bar, Stamper stamp, int rbase = 0) {
+                                                  cplx *rows_lds, int *sync_flags, int tau, Stamper stamp) {
     using SG = SplitGeo<N, ROWS>;
     constexpr int H = SG::H, TH = SG::TH, P = kP, LC = Pass1<N>::kCompactLayers, T = plan_T(N);
     const int wv = __builtin_amdgcn_readfirstlane(tau / 64), rw = wv >> 1, w = wv & 1;  // row inside the item, parity
     const int tp = tau % 64, t = 2 * tp + w;                                              // physical lane, logical lane of the N plan
-    cplx *vrow = rows_lds + (w * LROWS + rbase + rw) * SG::R;
+    cplx *vrow = rows_lds + (w * ROWS + rw) * SG::R;
     const uint32_t plane = (uint32_t)N * N;
     RowSync<H> rs;    // inside one wave: compiler ordering only
     RowSync<N> pair;  // the two waves of a row (used by the pair that owns texel row 0 only)
@@ -896,7 +863,7 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     // E[k] +- W_N^k O[k] for k = xi + T m, m = 2g and 2g + 1 (chunk g of four): staged values of row q
-    const cplx *e_reg = rows_lds + (rbase + q) * SG::R, *o_reg = rows_lds + (LROWS + rbase + q) * SG::R;
+    const cplx *e_reg = rows_lds + q * SG::R, *o_reg = rows_lds + (ROWS + q) * SG::R;
     auto combine = [&](int m, cplx &lo, cplx &hi) {
         const cplx e = lds_read(e_reg + xi + T * m), o = lds_read(o_reg + xi + T * m);
         // W_N^(xi + T m) = W_N^xi * exp(2 pi i m / 16): two packed instructions where it is used.  (The base is made opaque so that
@@ -938,7 +905,7 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
     if (__builtin_amdgcn_readfirstlane(y) == 0) {
         const int xr = tp + TH * w;  // this lane's x' (mod T) in the join
         const cplx wxr = buf.tw_split[SG::TW + xr];
-        const cplx *e0 = rows_lds + (rbase + rw) * SG::R, *o0 = rows_lds + (LROWS + rbase + rw) * SG::R;
+        const cplx *e0 = rows_lds + rw * SG::R, *o0 = rows_lds + (ROWS + rw) * SG::R;
 #pragma unroll
         for (int Q = 1; Q <= 3; ++Q) {
             cplx d[P];
@@ -992,14 +959,14 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
         }
         OW_SCHED_FENCE();
         stamp(4 + 3 * L, d[0].x);  // layer input built (previous layer's stores issued)
-        if (L > 0) row_ifft_gated<H>(d, tp, vrow, tw_lds, rs, [&] { bar.sync(); });  // (gate: the staged rows have been drained by every wave of the item)
+        if (L > 0) row_ifft<H, true>(d, tp, vrow, tw_lds, rs);  // (block gate: the staged rows have been drained by every wave)
         else row_ifft<H, false>(d, tp, vrow, tw_lds, rs);
         stamp(5 + 3 * L, d[0].x);  // transformed
         rs.sync();
 #pragma unroll
         for (int o = 0; o < P; ++o) vrow[tp + TH * o] = d[OutMap<H>::slot_of(o)];
-        bar.sync();
-        stamp(6 + 3 * L, 0.0f);  // staged, item barrier passed
+        lds_barrier();
+        stamp(6 + 3 * L, 0.0f);  // staged, block barrier passed
         if (L == LC - 1) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) store_chunk(L, g);
@@ -1018,37 +985,35 @@ __global__ __launch_bounds__((SplitGeo<N, ROWS>::kThreads), 4) void k_pass1c_spl
     p1_block_to_rows<N, kWgRows / ROWS>(slot, row0);
     const CascadeFrame cf = args.c[slot];
     fetch_arguments(buf, cf);
-    BlockBarrier bar;
     pass1c_split_item<N, ROWS, AUX_T, AUX_H>(buf, cf, cf.time, slot, row0, args.c[0].fault, lds, lds + SG::TW, reinterpret_cast<int *>(lds + SG::kLdsCplx),
-                                             (int)threadIdx.x, bar, [&](int k, float keep) { ws.at(k, keep); });
+                                             (int)threadIdx.x, [&](int k, float keep) { ws.at(k, keep); });
     ws.write(stamps, SG::kThreads / 64, (unsigned long long)row0);
 }
 
 // ===================================================================================================
-// TICK PAIRS at N = 2048 (k_tick_pair_c_split): one launch = pass 2 of one cascade (k_pass2c's 16-wave blocks: 8 columns, rows paired through
-// RowSync) and pass 1 of the NEXT cascade of the stream -- the tick's next cascade, or the first cascade one tick later -- in the split plan's
-// 4-row items, TWO ITEMS PER BLOCK: the two halves of one 8-row unit run side by side in the block's sixteen waves, each with its own row
-// regions, its own pair flags and its own arrival counter (SubBlockBarrier), sharing the N/2-plan table.  They never meet at s_barrier
-// after the table's commit, so each half keeps the pace that made the 4-row blocks win on their own (two independent 8-wave blocks per CU
-// against one 16-wave block in lock step: 34.1 -> 29.3 - 30.9 us per cascade), and because both halves of every 64-byte segment of T now
-// leave from ONE CU they meet in one L2 by construction.  Both kinds of block take one CU each (148 KB / 152 KB of LDS) and alternate in
-// chunks of 8 (one block per XCD), as in k_tick_pair_c: while one half of the chip is in pass 2's memory phases the other half transforms.
-// One cascade's compact intermediate (84 MB) is written by one launch and read by the next, with 48 MB of spectra and 16 MB of foam streaming
-// past: it is consumed while still resident in the Infinity Cache.  Same item bodies as k_pass1c_split / k_pass2c: bit-identical results.
+// TICK PAIRS at N = 2048 (k_tick_pair_c_split): one launch = pass 2 of one cascade and pass 1 of the NEXT cascade of the stream (the tick's
+// next cascade, or the first cascade one tick later), both in 8-WAVE blocks: pass 1 in the split plan's 4-row items (k_pass1c_split's own
+// block), pass 2 in blocks of 4 columns (k_pass2c's item body on half as many rows).  Either kind takes 78 KB of LDS -- for pass 2 that needs
+// the HALF twiddle table (ow_device.h): with the full 16 KB table a 4-column block is 86 KB and a CU holds one -- so a CU holds TWO blocks, of
+// either kind, and the chunks of 8 blocks (one per XCD) alternate between the passes: every CU runs a pass-1 block beside a pass-2 block,
+// one in its transforms while the other waits for memory.  That is what the 1024^2 pair kernel lives on, and what the first form of this
+// kernel (16-wave blocks, one per CU: profiles/r04_2048_pair_v1_16wave_blocks_rejected.txt) lacked.  One cascade's compact intermediate
+// (84 MB) is written by one launch and read by the next while still resident in the Infinity Cache.  Same item bodies as k_pass1c_split /
+// k_pass2c: bit-identical results (tests/test_tick_groups.py).
 // ===================================================================================================
 template <int N>
 struct PairSplitGeo {
     using SG = SplitGeo<N, 4>;
-    static constexpr int kSub = kWgRows / 4;                                        // items per block: 2
-    static constexpr int kItemFlags = 2 * 4;                                        // pair flags of one item (ints)
-    static constexpr int kP1Cplx = SG::TW + kSub * 2 * 4 * SG::R;                   // table + both items' row regions
-    static constexpr int kP1Ints = kSub * kItemFlags + kSub;                        // pair flags + one arrival counter per item
-    static constexpr int kP2Cplx = plan_wg_lds_cplx(N) + plan_sync_flag_cplx(N, kWgRows);
-    static constexpr int kLdsCplx = (kP1Cplx + (kP1Ints + 1) / 2) > kP2Cplx ? (kP1Cplx + (kP1Ints + 1) / 2) : kP2Cplx;
-    static_assert(plan_wg_threads(N) == kSub * SG::kThreads, "pass 2's block holds exactly two 4-row split items");
+    static constexpr int kThreads = SG::kThreads;                     // 512: a 4-row split item = 8 waves
+    static constexpr int kCols = kThreads / plan_T(N);                // columns of a pass-2 block: 4
+    static constexpr int kP1Cplx = SG::kLdsCplx + plan_sync_flag_cplx(N, 4);
+    static constexpr int kP2Tw = p2c_table_total(N);
+    static constexpr int kP2Cplx = kP2Tw + kCols * plan_region_cplx(N) + plan_sync_flag_cplx(N, kCols);
+    static constexpr int kLdsCplx = kP1Cplx > kP2Cplx ? kP1Cplx : kP2Cplx;
+    static_assert(kCols * plan_T(N) == kThreads && 2 * kLdsCplx * (int)sizeof(cplx) <= 160 * 1024, "two blocks per CU, of either kind");
 };
 template <int N, bool F32, bool STAMPS = false>
-__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c_split(DeviceBuffers buf, FrameArgs args, TickGroupArgs g, Stamp *stamps = nullptr) {
+__global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_split(DeviceBuffers buf, FrameArgs args, TickGroupArgs g, Stamp *stamps = nullptr) {
     static_assert(plan_split(N), "rows that span two waves (N = 2048)");
     using PG = PairSplitGeo<N>;
     using SG = typename PG::SG;
@@ -1068,44 +1033,35 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c_split(Dev
             index -= both / 2;
         }
     }
-    if (!first) {  // ---- pass 2 of 8 columns: k_pass2c's block ----
+    if (!first) {  // ---- pass 2 of 4 columns ----
         cplx *tw_lds = lds;
-        cplx *rows_lds = lds + plan_tw_total(N);
+        cplx *rows_lds = lds + PG::kP2Tw;
         const int tau = threadIdx.x;
-        int *sync_flags = reinterpret_cast<int *>(lds + plan_wg_lds_cplx(N));
+        int *sync_flags = reinterpret_cast<int *>(lds + PG::kP2Tw + PG::kCols * plan_region_cplx(N));
         RowSync<N> rs;
         rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
         rs.watch(buf.status, args.c[0].fault);
-        init_row_sync<N>(sync_flags, kWgRows);
-        constexpr int BPC = N / kWgRows;
-        const int slot = index / BPC, row0 = (index % BPC) * kWgRows;
+        init_row_sync<N>(sync_flags, PG::kCols);
+        constexpr int BPC = N / PG::kCols;
+        const int slot = index / BPC, row0 = (index % BPC) * PG::kCols;
         const CascadeFrame cf = args.c[g.first2 + slot];
         fetch_arguments(buf, cf);
-        TwPrefetch<N> twp;
-        tw_fetch<N>(twp, buf.tw);
+        TablePrefetch<PG::kP2Tw, PG::kThreads> twp;
+        twp.fetch(p2c_table<N>(buf));
         uint32_t foam_pk[kP / 2];
-        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, tau, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
-        ws.write(stamps, plan_wg_threads(N) / 64, 2000ull);
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2[0] + slot, row0, tau, tw_lds, rows_lds, rs, [&] { twp.commit(tw_lds); }, foam_pk);
+        ws.write(stamps, PG::kThreads / 64, 100000ull);
         return;
     }
-    // ---- pass 1 of one 8-row unit: its two 4-row items side by side ----
-    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x / SG::kThreads), tau = (int)threadIdx.x % SG::kThreads;
+    // ---- pass 1 of 4 rows: k_pass1c_split's block (the two blocks of an 8-row unit 8 indices apart: same XCD, one after the other) ----
     int slot, row0;
-    p1_index_to_rows<N, 1>(index, slot, row0);
-    row0 += sub * 4;
+    p1_index_to_rows<N, kWgRows / 4>(index, slot, row0);
     const int launch_slot = g.first1 + slot;
     const CascadeFrame cf = args.c[launch_slot];
     fetch_arguments(buf, cf);
-    cplx *tw_lds = lds;
-    cplx *rows_lds = lds + SG::TW;  // both items' regions: [E regions of the unit's 8 rows][O regions]; this item's rows are 4 sub .. 4 sub + 3 of them
-    int *ints = reinterpret_cast<int *>(lds + PG::kP1Cplx);
-    int *sync_flags = ints + sub * PG::kItemFlags, *arrivals = ints + PG::kSub * PG::kItemFlags + sub;
-    if (tau == 0) *arrivals = 0;  // (made visible by the block barrier of the twiddle commit, like the pair flags)
-    SubBlockBarrier<SG::kThreads / 64> bar;
-    bar.attach(arrivals, buf.status);
-    pass1c_split_item<N, 4, kAuxDefault, kAuxDefault, kWgRows>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, args.c[0].fault, tw_lds, rows_lds, sync_flags,
-                                                               tau, bar, [&](int k, float keep) { ws.at(k, keep); }, sub * 4);
-    ws.write(stamps, plan_wg_threads(N) / 64, 1000ull + (unsigned long long)row0);
+    pass1c_split_item<N, 4, kAuxDefault, kAuxDefault>(buf, cf, g.time1[0][launch_slot], g.tbase1[0] + slot, row0, args.c[0].fault, lds, lds + SG::TW,
+                                                      reinterpret_cast<int *>(lds + SG::kLdsCplx), (int)threadIdx.x, [&](int k, float keep) { ws.at(k, keep); });
+    ws.write(stamps, PG::kThreads / 64, 1000ull + (unsigned long long)row0);
 }
 
 // ===================================================================================================

@@ -21,6 +21,7 @@ struct DeviceBuffers {
     cplx *pcol;     // [launch slot][N]     P(ky) of texel column id.x = 0, in pass-2 lane order (Pass2::pcol_index)
     cplx *rrow;     // [launch slot][N x'][4] row transforms Q1..Q3 of texel row id.y = 0 (entry 0 unused)
     const cplx *tw_split; // split plan (N = 2048): [twiddle table of the N/2 plan][W_N^k, k = 0 .. N/2 - 1]; nullptr otherwise
+    const cplx *tw_half;  // half table (N = 2048, the compact pass 2: plan_twh_total(N) entries, ow_device.h "HALF TABLE"); nullptr otherwise
     uint32_t *status; // device status word (page-locked host memory, mapped): kernels OR kStatus* bits into it
 };
 

@@ -49,13 +49,12 @@ constexpr double kHostG = 9.81;  // wave_generator.gd:5
 struct ow_context {
     int n = 0, cascades = 0, layers = 0, device = 0;
     float depth = 20.0f;
-    bool no_merge = false;  // OW_FLAG_NO_TICK_GROUPS: one launch per pass, always
     int kernel_mode = 0;  // 0 = by batch size, 1 = standard, 2 = layer-parallel, 3 = compact-intermediate kernels (OW_FLAG_KERNELS_*)
     int last_family = 0;  // kernel family of the most recent batch
     hipStream_t stream = nullptr;
     bool own_stream = false, own_disp = false, own_norm = false;
     ow::DeviceBuffers buf{};
-    ow::cplx *tw_dev = nullptr, *tw_split_dev = nullptr;
+    ow::cplx *tw_dev = nullptr, *tw_split_dev = nullptr, *tw_half_dev = nullptr;
     // generator state per invocation of update() (wave_generator.gd:13-15).  The reference keeps a reference to the caller's
     // Array; a C caller's memory is only borrowed for the duration of a call, so the context keeps COPIES of the armed records
     // (ow_set_cascade_params / ow_get_cascade_params are the explicit form of "the parameter objects are live")
@@ -76,10 +75,6 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
-    // A lone tick (ow_update_all / ow_process callers: no look-ahead across ticks) of a compact-family batch in THREE launches instead of
-    // two: [pass 1 of half A] [pass 2 of A + pass 1 of half B: k_tick_pair_c] [pass 2 of B] -- independent work inside one tick shares a
-    // launch (0: off).  OW_DEBUG_SPLIT_TICK, read once by ow_create.
-    int split_lone_ticks = 0;
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
@@ -183,8 +178,6 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
     // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
-    c->split_lone_ticks = 0;
-    if (const char *e = getenv("OW_DEBUG_SPLIT_TICK")) c->split_lone_ticks = atoi(e);
     c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
@@ -380,8 +373,6 @@ void record_frame_constants(ow_context *c, int cascade, const ow_cascade_params 
     c->pc_valid[cascade] = true;
 }
 
-bool flags_no_merge(const ow_context *c) { return c->no_merge; }
-
 // _update() for a batch of cascade indices (wave_generator.gd:65-85)
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
@@ -451,28 +442,6 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         if (c->timing) {
             ow_status st = next_events(c, &ev);
             if (st != OW_OK) return st;
-        }
-        if (c->split_lone_ticks > 0 && (c->split_lone_ticks % 10) != 0 && !c->timing && part.c[0].fault == 0 && nb >= 2 && c->last_family == 3 && ow::tick_groups_supported(c->n) &&
-            !(flags_no_merge(c))) {
-            // three launches, same item bodies (bit-identical): A = the first a launch slots, B = the rest; scratch slot = launch slot
-            const int a = (c->split_lone_ticks % 10) == 2 ? 1 : (nb + 1) / 2;
-            ow::TickGroupArgs ga;
-            std::memset(&ga, 0, sizeof(ga));
-            ga.pair_compact = 1;
-            for (int i = 0; i < nb; ++i) ga.time1[0][i] = part.c[i].time;
-            const int first[4] = {0, a, nb}, stages = 3;
-            for (int st = 0; st < stages; ++st) {  // stage st: pass 2 of piece st - 1, pass 1 of piece st
-                ga.slots2 = st >= 1 ? first[st] - first[st - 1] : 0;
-                ga.first2 = st >= 1 ? first[st - 1] : 0;
-                ga.tbase2[0] = ga.first2;
-                ga.slots1 = st < 2 ? first[st + 1] - first[st] : 0;
-                ga.first1 = st < 2 ? first[st] : 0;
-                ga.tbase1[0] = ga.first1;
-                ga.d2 = ga.slots2 > 0;
-                ga.d1 = ga.slots1 > 0;
-                OW_HIP(ow::launch_tick_group(c->n, part, ga, c->buf, c->stream, ow::LaunchTiming{}));
-            }
-            continue;
         }
         const ow::LaunchTiming t1{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}, t2{ev ? ev[2] : nullptr, ev ? ev[3] : nullptr};
         OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t1));  // modulate + rows + transpose (:73-80)
@@ -577,7 +546,6 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
-    c->no_merge = (cfg->flags & OW_FLAG_NO_TICK_GROUPS) != 0;
     plan_tick_groups(c, cfg->flags);
     if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
@@ -604,9 +572,14 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->tw_dev, tw.size() * sizeof(ow::cplx));
     std::vector<ow::cplx> tw_split;
     if (ow::make_split_twiddles(c->n, tw_split)) { OW_ALLOC(c->tw_split_dev, tw_split.size() * sizeof(ow::cplx)); }
+    std::vector<ow::cplx> tw_half;
+    if (ow::make_half_twiddles(c->n, tw_half)) { OW_ALLOC(c->tw_half_dev, tw_half.size() * sizeof(ow::cplx)); }
 #undef OW_ALLOC
     c->buf.tw = c->tw_dev;
     c->buf.tw_split = c->tw_split_dev;
+    c->buf.tw_half = c->tw_half_dev;
+    if (c->tw_half_dev && hipMemcpyAsync(c->tw_half_dev, tw_half.data(), tw_half.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return bail(fail(OW_ERR_HIP, "twiddle upload failed"));
     if (c->tw_split_dev && hipMemcpyAsync(c->tw_split_dev, tw_split.data(), tw_split.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "twiddle upload failed"));
     // Vulkan images start undefined; foam must start from a defined state: zero
@@ -640,6 +613,7 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->buf.rrow);
     (void)hipFree(c->tw_dev);
     (void)hipFree(c->tw_split_dev);
+    (void)hipFree(c->tw_half_dev);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipFree(c->snap_dev);
@@ -742,7 +716,6 @@ namespace {
 // returns 0 = not usable, the ticks per launch (group_depth) for the tick groups, -1 for the compact family's tick pairs
 int tick_groups_usable(const ow_context *c, const ow_cascade_params *params, int count) {
     if (c->timing == 1 || c->inject_fault || c->pass_num_cascades_remaining != 0) return 0;
-    if (c->split_lone_ticks < 0 || c->split_lone_ticks >= 10) return 0;  // measurement: ow_run as a loop of lone ticks (10 + mode: split as mode; -1: two launches)
     int sizes[OW_MAX_CASCADES];
     const bool groups = ow::kernel_family(c->n, count, c->kernel_mode) == 4 && count <= c->group_max_count;
     const bool pairs = !groups && c->pair_slots > 0 && pair_batches(c, count, sizes) > 0;

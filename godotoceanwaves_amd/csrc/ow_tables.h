@@ -42,6 +42,27 @@ inline bool make_split_twiddles(int n, std::vector<cplx> &tw) {
     return false;
 }
 
+// half table (ow_device.h, fft_stage_compute<N, J, TWH>): [15][64] exp(+2 pi i p k / N) for the first wave's lanes p < 64, then the stage-1
+// block of the full table unchanged; FP64 rounded once to FP32
+template <int N>
+inline void fill_half_twiddles(std::vector<cplx> &tw) {
+    std::vector<cplx> full;
+    fill_twiddles<N>(full);
+    tw.assign(plan_twh_total(N), cplx{1.0f, 0.0f});
+    const int R = plan_R(N, 0), m = plan_m(N, 0);
+    for (int k = 1; k < R; ++k)
+        for (int p = 0; p < kTwhCols; ++p) tw[(k - 1) * kTwhCols + p] = full[(k - 1) * m + p];
+    for (int i = 0; i < plan_tw_size(N, 1); ++i) tw[plan_twh_off(N, 1) + i] = full[plan_tw_off(N, 1) + i];
+}
+inline bool make_half_twiddles(int n, std::vector<cplx> &tw) {
+    if (n == 2048) {
+        fill_half_twiddles<2048>(tw);
+        return true;
+    }
+    tw.clear();
+    return false;
+}
+
 inline bool make_twiddles(int n, std::vector<cplx> &tw) {
     switch (n) {
         case 128: fill_twiddles<128>(tw); return true;

@@ -19,13 +19,29 @@ template <int N, int NT>
 struct Block {
     static constexpr int Tn = plan_T(N), P = kP;
     std::vector<cplx> lds = std::vector<cplx>(plan_region_cplx(N) * (NT / Tn));
-    std::vector<cplx> tw;
-    Block() { fill_twiddles<N>(tw); }
+    std::vector<cplx> tw, twh;
+    bool half_table = false;  // N = 2048: the compact pass 2's half twiddle table (ow_device.h "HALF TABLE")
+    Block() {
+        fill_twiddles<N>(tw);
+        if constexpr (plan_row_spans_waves(N)) fill_half_twiddles<N>(twh);
+    }
     cplx *row(int tau) { return lds.data() + (tau / Tn) * plan_region_cplx(N); }
 
     // row IFFT of d[tau][P] for all threads in lockstep (mirrors row_ifft<N> in ow_frame_kernels.h;
     // every loop below is one phase between two row_sync()s)
     void row_ifft(cplx (*d)[P]) {
+        if constexpr (plan_row_spans_waves(N)) {
+            if (half_table) {
+                for (int l = 0; l < NT; ++l) fft_stage_compute<N, 0, true>(d[l], l % Tn, twh.data());
+                for (int l = 0; l < NT; ++l) fft_stage_write<N, 0>(d[l], l % Tn, row(l));
+                for (int l = 0; l < NT; ++l) fft_stage_read<N, 1>(d[l], l % Tn, row(l));
+                for (int l = 0; l < NT; ++l) fft_stage_compute<N, 1, true>(d[l], l % Tn, twh.data());
+                for (int l = 0; l < NT; ++l) fft_stage_write<N, 1>(d[l], l % Tn, row(l));
+                for (int l = 0; l < NT; ++l) fft_stage_read<N, 2>(d[l], l % Tn, row(l));
+                for (int l = 0; l < NT; ++l) fft_stage_compute<N, 2>(d[l], l % Tn, tw.data());
+                return;
+            }
+        }
         for (int l = 0; l < NT; ++l) fft_stage_compute<N, 0>(d[l], l % Tn, tw.data());
         for (int l = 0; l < NT; ++l) fft_stage_write<N, 0>(d[l], l % Tn, row(l));
         for (int l = 0; l < NT; ++l) fft_stage_read<N, 1>(d[l], l % Tn, row(l));
@@ -60,9 +76,10 @@ struct Block {
 };
 
 template <int N>
-void rows_fft(const float *in, float *out, int rows) {
+void rows_fft(const float *in, float *out, int rows, bool half_table = false) {
     constexpr int Tn = plan_T(N), P = kP, NT = plan_wg_threads(N);
     Block<N, NT> w;
+    w.half_table = half_table;
     static cplx d[NT][P];
     for (int r0 = 0; r0 < rows; r0 += kWgRows) {
         for (int l = 0; l < NT; ++l) {
@@ -367,6 +384,12 @@ int emul_tick_items(int n, int slots, int *out) {
 }
 int emul_tick_items_2(int n, int slots) { return n == 256 ? TickPlan<256>::items_2(slots) : n == 512 ? TickPlan<512>::items_2(slots) : TickPlan<1024>::items_2(slots); }
 
+
+// the 2048-point row transform with the compact pass 2's half twiddle table
+int emul_rows_fft_half_table(const float *in, float *out, int rows) {
+    rows_fft<2048>(in, out, rows, true);
+    return 0;
+}
 
 int emul_rows_fft(int n, const float *in, float *out, int rows) {
     switch (n) {

@@ -48,3 +48,36 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     assert um["ms_per_step"] >= 0.9 * d["ms_per_step"] and 0.0 < um["frac"] < 0.85 and um["value"] > 0 and len(um["kernels"]) == 2
     assert res["reused_bytes"] == res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"] and res["infinity_cache_bytes"] == 256 << 20
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    # round 4: the CPU leg runs first, the GPU work is one contiguous stretch and says how long it was
+    assert d["timed_region_s"] == d["timed_seconds"] > 0 and d["gpu_phase_s"] > d["timed_region_s"]
+    assert d["timed_ticks_per_region"] == 40 and d["regions_per_sync"] == 1 and d["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_carries_the_scaling_references(tmp_path):
+    """The N > 1 rank code on the ONE GPU of the box (gloo, both ranks on GPU 0: control flow only, the numbers mean nothing): the default
+    is the strong-scaling series of BASELINE config C4 (8 cascades shared out: 4 per GPU at N = 2), the gather keeps its cadence inside a
+    region of R x K ticks, and the line carries the references that answer the scaling question on its own."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--min-time", "0.05", "--backend", "gloo", "--share-gpu",
+                        "--prime-ms", "50"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "strong" and d["config"]["cascades_per_gpu"] == 4
+    assert "rehearsal" in d["config"] and "cpu_baseline" not in d
+    k = d["gather"]["every_ticks"]
+    assert k >= 1 and d["timed_ticks_per_region"] >= 4 * k and d["timed_ticks_per_region"] % 20 == 0
+    assert d["regions_per_sync"] == d["timed_ticks_per_region"] // 20 == d["gather"]["regions_per_sync"]
+    assert abs(d["value"] - 8 * d["timed_ticks_per_region"] / (d["ms_per_step"] * 1e-3 * d["timed_ticks_per_region"])) / d["value"] < 1e-3
+    for key in ("no_gather", "gather_every_tick", "per_gpu_alone", "one_gpu_whole_job", "speedup_with_gather", "speedup_no_gather",
+                "speedup_vs_one_gpu_with_gather", "speedup_vs_one_gpu_no_gather", "parallel_efficiency", "headline_basis"):
+        assert key in d, key
+    assert d["one_gpu_whole_job"]["cascades"] == 8 and d["one_gpu_whole_job"]["value"] > 0
+    assert d["per_gpu_alone"]["min"] <= d["per_gpu_alone"]["value"] <= d["per_gpu_alone"]["max"]
+    assert abs(d["speedup_no_gather"] - d["no_gather"]["value"] / d["per_gpu_alone"]["value"]) < 0.02 * d["speedup_no_gather"]

@@ -37,6 +37,7 @@ def emul():
     f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
     u16p = np.ctypeslib.ndpointer(np.uint16, flags="C")
     E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
+    E.emul_rows_fft_half_table.argtypes = [f32p, f32p, C.c_int]
     E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p, f32p]
     E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_frame_compact.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
@@ -65,6 +66,20 @@ def test_row_ifft_is_unnormalised_inverse_dft(emul, n):
     assert emul.emul_rows_fft(n, x, y, rows) == 0
     ref = np.fft.ifft(x[..., 0].astype(np.float64) + 1j * x[..., 1], axis=1) * n
     assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 5e-7
+
+
+def test_half_twiddle_table_of_the_2048_pass_2(emul):
+    """ow_device.h "HALF TABLE": the row's second wave takes the first wave's stage-0 twiddles times exp(2 pi i k / 32) instead of its own
+    half of a 16 KB table (so that a 4-column block of pass 2 fits a CU twice).  Still the unnormalised inverse DFT, to the same accuracy,
+    and within a few FP32 ulps of the full-table transform."""
+    rng = np.random.default_rng(5)
+    n, rows = 2048, 8
+    x = rng.standard_normal((rows, n, 2)).astype(np.float32)
+    y, full = np.zeros_like(x), np.zeros_like(x)
+    assert emul.emul_rows_fft_half_table(x, y, rows) == 0 and emul.emul_rows_fft(n, x, full, rows) == 0
+    ref = np.fft.ifft(x[..., 0].astype(np.float64) + 1j * x[..., 1], axis=1) * n
+    assert H.relmax(y[..., 0] + 1j * y[..., 1], ref) < 5e-7
+    assert H.relmax(y, full) < 3e-7 and not np.array_equal(y, full)   # a different rounding of half the stage-0 twiddles, nothing more
 
 
 @pytest.mark.parametrize("intermediate", ["reference_layout", "compact", "reference_layout_lp", "compact_lp"])
