@@ -75,6 +75,7 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
+    int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
     // into one group; the scratch buffers hold 2 * depth * count cascades then
@@ -178,6 +179,8 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
     // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
+    c->pair_tick_block = 0;
+    if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));  // measurement knob: 1 = tick-major
     c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
@@ -829,6 +832,23 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
 // `ticks` >= 2 consecutive ow_update_all() ticks of the compact family as tick pairs: the run is a stream of batches (B per tick, launch
 // slots in the order ow_update_all takes them), launch i = [pass 2 of batch i - 1 + pass 1 of batch i]; batch i's intermediate lives in
 // scratch slots (i mod 2) * pair_slots ...
+// ORDER OF THE STREAM.  Cascades are independent and a batch's ticks only have to follow each other, so any interleaving of the batches'
+// tick sequences leaves the same bits behind.  Tick-major (all batches of tick t, then tick t + 1) is the default.  At 2048^2 (one cascade
+// per batch, 48 MB of spectra and 16 MB of foam each) a tick of two or more cascades streams more than the 256 MiB Infinity Cache holds
+// next to the two intermediates, so tick-major order re-reads EVERYTHING from DRAM every tick; the stream goes CASCADE-major in blocks of
+// kPairTickBlock ticks instead -- cascade 0 through 64 ticks, then cascade 1 through the same 64, ... -- and 63 launches out of 64 find
+// their spectra (read by the previous launch), their foam (written by it) and their intermediate in the cache, exactly like a one-cascade
+// run.  Measured (profiles/r04_2048_pairs.txt, us per tick, one launch per pass | pairs tick-major | cascade-major in blocks of 8 | of 64):
+// 2048^2 x 2 123.8 | 140.2 | 119.6 | 117.2;  x 4 260.7 | 275.2 | 243.1 | 235.5;  x 8 554.9 | 520.5 | 481.3 | 471.9 -- bit-identical maps.
+// Only the final state of a run is defined for a caller (ow_run = `frames` ow_update_all calls back to back), and it is the same.
+constexpr int kPairTickBlock = 64;
+void advance_slots(double delta, ow_cascade_params *params, int count, int first_slot, int nslots, float *time_out) {  // launch slot i = cascade count-1-i
+    for (int i = first_slot; i < first_slot + nslots; ++i) {
+        ow_cascade_params &p = params[count - 1 - i];
+        p.time += delta;  // wave_generator.gd:103, one FP64 add per tick, in order
+        time_out[i] = (float)p.time;
+    }
+}
 ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
     int sizes[OW_MAX_CASCADES], first[OW_MAX_CASCADES];
     const int B = pair_batches(c, count, sizes);
@@ -836,23 +856,37 @@ ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params,
         first[b] = at;
         at += sizes[b];
     }
+    // the stream: which batch each launch's pass 1 belongs to
+    const int block = c->pair_tick_block > 0 ? c->pair_tick_block : (ow::kernel_streams_from_dram(c->n) ? kPairTickBlock : 1);
+    const int D = B > 1 ? std::min(ticks, block) : 1;
+    std::vector<uint8_t> order;
+    order.reserve((size_t)ticks * B);
+    for (int t0 = 0; t0 < ticks; t0 += D)
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < std::min(D, ticks - t0); ++j) order.push_back((uint8_t)b);
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.pair_compact = 1;
-    ow::FrameArgs args;
-    const int total = ticks * B;
+    // the foam rates of this delta (wave_generator.gd:104-106): the same for every tick of the run
+    for (int i = 0; i < count; ++i) {
+        ow_cascade_params &p = params[i];
+        p.foam_grow_rate = delta * p.foam_amount * 7.5;
+        const double d = 10.0 - p.foam_amount;
+        p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
+    }
+    ow::FrameArgs args = run_frame_args(params, count);
+    const int total = (int)order.size();
     for (int i = 0; i <= total; ++i) {
         ga.slots2 = ga.slots1 = 0;
         if (i >= 1) {
-            const int b = (i - 1) % B;
+            const int b = order[i - 1];
             ga.first2 = first[b];
             ga.slots2 = sizes[b];
             ga.tbase2[0] = ((i - 1) & 1) * c->pair_slots;
         }
         if (i < total) {
-            const int b = i % B;
-            if (b == 0) advance_tick(delta, params, count, ga.time1[0]);  // a new tick begins: every launch slot's time
-            if (i == 0) args = run_frame_args(params, count);             // (after the first advance: the foam rates of this delta)
+            const int b = order[i];
+            advance_slots(delta, params, count, first[b], sizes[b], ga.time1[0]);  // this batch's next tick
             ga.first1 = first[b];
             ga.slots1 = sizes[b];
             ga.tbase1[0] = (i & 1) * c->pair_slots;
