@@ -103,7 +103,7 @@ constexpr int plan_tw_total(int N) { return plan_tw_off(N, plan_S(N) - 1); }
 // Time did not move for any of them, at any size, on the same box (1024^2 x 4 53.5 vs 53.6 us, 2048^2 x 1 63.3 vs 63.1): the LDS is not on
 // the critical path of these kernels.  And map 2's lane part costs eight integer operations per stage where this one costs three, which
 // pushes k_pass1c_split<2048> and k_tick_group_c_lp<256> from 126 to 128 VGPRs plus 16 - 20 bytes of scratch.  A change that buys nothing
-// and spills is not shipped: the map of rounds 1-2 stays, the others remain selectable for A/B builds.
+// and spills is not shipped: the map of rounds 1-2 stays, the others remain selectable for A/B builds (profiles/EXPERIMENTS.md).
 #ifndef OW_LDS_SLOT_MAP
 #define OW_LDS_SLOT_MAP 0  // 0: e + (e >> 4) (shipped), 1: e + (e >> 5), 2: bits 3 / 4 swapped + (e >> 5), second exchange map 1   (scripts/build_variant.sh mapN -DOW_LDS_SLOT_MAP=N)
 #endif

@@ -51,7 +51,7 @@ __device__ __forceinline__ void lds_barrier() {
 // rendezvous through two LDS words (each wave publishes a monotonically increasing epoch after its own LDS traffic has
 // completed, and polls its partner's) instead of an s_barrier, which would put all 16 waves of the block in lockstep
 // at every exchange although only pairs exchange data.
-// polls of the partner's epoch word before the waiting wave starts to sleep between polls (measured, round 3: see DESIGN.md section 8)
+// polls of the partner's epoch word before the waiting wave starts to sleep between polls (measured, round 3: profiles/EXPERIMENTS.md)
 #ifndef OW_ROWSYNC_FREE_POLLS
 #define OW_ROWSYNC_FREE_POLLS 0
 #endif

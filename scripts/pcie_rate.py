@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rates of the host hand-off (DESIGN.md "host hand-off"): what a consumer that needs the maps in host
+"""PCIe-inclusive rates of the host hand-off: what a consumer that needs the maps in host
 memory (RenderingDevice.texture_update) gets, next to the in-HBM rate bench.py reports.
   a) every tick of 1024^2 x 4, all four layers read back, pipelined (readback of tick k overlaps tick k+1)
   b) the reference's schedule: one cascade per rendered frame, that layer read back each frame
