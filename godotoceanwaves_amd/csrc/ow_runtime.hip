@@ -75,6 +75,7 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
+    bool pair_full_batches = false;  // measurement knob (OW_DEBUG_PAIR_FULL, read once): full-size batches also where two of them overflow the Infinity Cache
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
@@ -163,7 +164,7 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
         // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
         const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
         // (2048^2: one cascade per batch is the only shape k_tick_pair_c_split has, and nothing but the intermediate is resident there anyway)
-        if (c->n <= 1024 && B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
+        if (c->n <= 1024 && !c->pair_full_batches && B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
         return B;
     }
     return 0;
@@ -179,6 +180,7 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
     // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
+    c->pair_full_batches = getenv("OW_DEBUG_PAIR_FULL") != nullptr;
     c->pair_tick_block = 0;
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));  // measurement knob: 1 = tick-major
     c->pair_texels = kPairTexels;

@@ -1,20 +1,34 @@
 #!/bin/bash
-# closing state of a round: default bench line, the rocprofv3 kernel trace of the same command on the same box, PMC passes (separate runs),
-# the sweep over the BASELINE configurations, the GPU suite's tail.    R=r03 bash scripts/gpu_closing.sh
+# closing state of a round: the GPU suite, the default bench line, the rocprofv3 kernel trace of the same command on the same box (and of the
+# 2048^2 x 4 configuration), PMC passes (separate runs, no tracing domains beside them), the sweep over north_star's grid, a slice of the fuzz.
+#   R=r04 bash scripts/gpu_closing.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
-R=${R:-r03}; O=gpurun_out/${R}_closing; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json
-rm -rf $O/trace $O/trace2048 $O/pmc1 $O/pmc2
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline) > $O/trace.log 2>&1
+R=${R:-r04}; O=gpurun_out/${R}_closing; mkdir -p $O; export TMPDIR=/tmp
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; tail -c 300 $O/bench_driver_cmd.json; echo
+rm -rf $O/trace $O/trace2048 $O/pmc
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --min-time 0.5) > $O/trace.log 2>&1
 python scripts/rocprof_summary.py $O/trace $O/kernel_trace_1024x4.txt; head -12 $O/kernel_trace_1024x4.txt | cut -c1-150
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace2048" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --map-size 2048 --steps 300 --warmup 30) > $O/trace2048.log 2>&1
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace2048" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --map-size 2048 --steps 300 --warmup 30 --min-time 0.5) > $O/trace2048.log 2>&1
 python scripts/rocprof_summary.py $O/trace2048 $O/kernel_trace_2048x4.txt; head -8 $O/kernel_trace_2048x4.txt | cut -c1-150
-# PMC: counters in their own runs, no tracing domains beside them (two passes: the counters do not fit one)
-(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE -d "$GRAFT_REPO_ROOT/$O/pmc1" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-unmerged --steps 200 --warmup 20 --min-time 0.05 --prime-ms 50) > $O/pmc1.log 2>&1
-python scripts/rocprof_summary.py $O/pmc1 $O/pmc_fetch_write_1024x4.txt; grep -E "k_tick_pair_c|k_pass" $O/pmc_fetch_write_1024x4.txt | cut -c1-170 | head
-timeout 1500 python bench.py --sweep --steps 500 --warmup 50 --sweep-out $O/sweep.jsonl > $O/sweep.log 2>&1; python - <<PY
+# PMC: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace beside them and nothing else
+mkdir -p $O/pmc
+for cfg in "1024 4 21" "2048 4 65" "2048 1 21" "1024 8 21" "256 4 81"; do
+  set -- $cfg
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=$O/pmc/n$1x$2_$ctr
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d "$GRAFT_REPO_ROOT/$d" -o p -- python "$GRAFT_REPO_ROOT/scripts/drive.py" --map-size $1 --cascades $2 --frames $3 --warmup 2) > $d.log 2>&1
+    echo "$cfg $ctr rc=$?"
+  done
+done
+python scripts/rocprof_summary.py $O/pmc $O/pmc_fetch_write.txt
+grep -E "^## |FETCH_SIZE|WRITE_SIZE" $O/pmc_fetch_write.txt | grep -E "^## |k_tick|k_pass" | cut -c1-170
+rm -rf $O/trace $O/trace2048 $O/pmc/*/*.db 2>/dev/null; find $O -name "*.db" -delete
+rm -f $O/sweep_grid.jsonl
+timeout 1800 python bench.py --sweep-grid --steps 500 --warmup 50 --min-time 0.3 --cpu-seconds 3 --prime-ms 300 --sweep-out $O/sweep_grid.jsonl > $O/sweep.log 2>&1; python - <<PY
 import json
-for l in open("$O/sweep.jsonl"):
-    d=json.loads(l); r=d["roofline"]; print(d["config"]["map_size"], d["config"]["cascades_per_gpu"], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["tick"]["frac"], r.get("unmerged",{}).get("ms_per_step"), d.get("cpu_baseline",{}).get("value"))
+for l in open("$O/sweep_grid.jsonl"):
+    d=json.loads(l); r=d["roofline"]; print(d["config"]["map_size"], d["config"]["cascades_per_gpu"], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["tick"]["frac"], r.get("unmerged",{}).get("ms_per_step"), r.get("unmerged",{}).get("frac"), d.get("cpu_baseline",{}).get("value"))
 PY
+timeout 900 python scripts/fuzz_parity.py 40 401 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt

@@ -37,9 +37,15 @@ if __name__ == "__main__":
     cfgs = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(2048, c) for c in (1, 2, 3, 4, 6, 8)]
     for n, c in cfgs:
         row = []
-        for label, merged, block in (("one launch per pass", "0", None), ("pairs tick-major", "1", "1"), ("pairs cascade-major x8", "1", "8"), ("x64", "1", "64")):
+        variants = [("one launch per pass", "0", None, False), ("pairs tick-major", "1", "1", False), ("pairs cascade-major x8", "1", "8", False), ("x64", "1", "64", False)]
+        if n <= 1024:  # multi-batch ticks below 2048^2: also full-size batches where the runtime would halve them
+            variants += [("x64, full-size batches", "1", "64", True), ("tick-major, full-size batches", "1", "1", True)]
+        for label, merged, block, full in variants:
             env = dict(os.environ)
             env.pop("OW_DEBUG_PAIR_TICK_BLOCK", None)
+            env.pop("OW_DEBUG_PAIR_FULL", None)
+            if full:
+                env["OW_DEBUG_PAIR_FULL"] = "1"
             if block:
                 env["OW_DEBUG_PAIR_TICK_BLOCK"] = block
             r = subprocess.run([sys.executable, __file__, "--child", str(n), str(c), merged], env=env, capture_output=True, text=True)

@@ -9,5 +9,7 @@ hipcc $F -DKBENCH_N=2048 tools/kbench.hip -o tools/kbench_2048 &
 hipcc $F -I tools -DKS_N=256 tools/kbench_small.hip -o tools/kbench_small_256 &
 hipcc $F -I tools -DKS_N=512 tools/kbench_small.hip -o tools/kbench_small_512 &
 hipcc $F tools/kbench_2048pair.hip -o tools/kbench_2048pair &
+hipcc $F -I tools -DKS_N=256 tools/kbench_solo.hip -o tools/kbench_solo_256 &
+hipcc $F -I tools -DKS_N=512 tools/kbench_solo.hip -o tools/kbench_solo_512 &
 wait
 ls -la tools/kbench tools/kbench_2048 tools/kbench_small_256 tools/kbench_small_512
