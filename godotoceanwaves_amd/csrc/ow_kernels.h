@@ -61,9 +61,6 @@ hipError_t launch_pass2(int n, int slots, int mode, const FrameArgs &args, const
 // filled in by the launcher.
 bool tick_groups_supported(int n);
 bool tick_pairs_supported(int n);
-// map sizes at which a tick of several batches cannot keep anything but the intermediate in the Infinity Cache (2048^2: 64 MB of spectra and
-// foam per cascade): ow_run orders its stream of batches cascade-major there (ow_runtime.hip run_tick_pairs)
-inline bool kernel_streams_from_dram(int n) { return n >= 2048; }  // map sizes with a tick-pair kernel (k_tick_pair_c; at 2048 k_tick_pair_c_split)
 int tick_group_pipe_blocks(int n, int slots);  // pass-2 blocks of the pipelined form (0: not available at this map size)
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s,
                              const LaunchTiming &lt = LaunchTiming{});

@@ -75,7 +75,6 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
-    bool pair_full_batches = false;  // measurement knob (OW_DEBUG_PAIR_FULL, read once): full-size batches also where two of them overflow the Infinity Cache
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
@@ -135,39 +134,26 @@ int batch_size(const ow_context *c, int count) {
 // (with 1 GiB instead -- depth 4 up to 1024^2 x 2 -- nothing changes where it matters: 1024^2 x 2 39.4 vs 39.4 us on k_pass1c + k_pass2c,
 // x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
 constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
-// Ticks of the compact family go out as tick pairs (k_tick_pair_c: pass 2 of one batch and pass 1 of the next in one launch), in
-// equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 7 is two batches (3 + 2, 3 + 3, 4 + 3).  The scratch is two batches deep:
-// at 4 Mi texels that is 160 MiB of intermediate in flight, which the Infinity Cache still holds next to the spectra (12 B/texel of
-// every cascade of the tick, read once per tick).  Multi-batch ticks are off where ONE batch of intermediate next to the spectra fits
-// kPairResidentBytes and two do not -- the line sits between what was measured on either side (us per tick, pairs | one launch per
-// pass): 1024^2 x 7 (84 MiB of spectra + 160 MiB) 103.0 | 109.2 steady; x 8 (96 + 160) 115.5 - 125.0, varying from context to context,
-// | 114.0 - 114.8.  A single batch of 5 or 6 Mi texels loses as well.  Map sizes up to 1024^2 (at 2048^2 the two passes want blocks of
-// different sizes; profiles/r02_tick_pairs_compact.txt).
-constexpr size_t kPairTexels = (size_t)4 << 20, kPairResidentBytes = (size_t)248 << 20;
+// Ticks of the compact family go out as tick pairs (k_tick_pair_c / k_tick_pair_c_split: pass 2 of one batch and pass 1 of the next in one
+// launch), in equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 8 is two batches (3 + 2, 3 + 3, 4 + 3, 4 + 4), at 2048^2 a batch is
+// one cascade.  The scratch is two batches deep: at 4 Mi texels 160 MiB of intermediate in flight, which the Infinity Cache holds next to the
+// batch's own spectra and foam (run_tick_pairs orders the stream so that a batch shares the cache with nothing but itself).  A single batch
+// of 5 or 6 Mi texels loses (profiles/r02_tick_pairs_compact.txt).
+constexpr size_t kPairTexels = (size_t)4 << 20;
 // the batches of one tick of `count` cascades (sizes[], larger first); 0 = no tick pairs for this count
 int pair_batches(const ow_context *c, int count, int *sizes) {
     const size_t pair_texels = c->pair_texels, pl = (size_t)c->n * c->n;
     if (count < 1 || !ow::tick_pairs_supported(c->n)) return 0;
-    // Where two full-size batches of intermediate next to the spectra do not fit the Infinity Cache (1024^2 x 8: 96 + 2 x 80 MiB), batches
-    // of half the size do (96 + 2 x 40): every launch is then one full round of blocks (256 of each pass at 1024^2) instead of two --
-    // measured (round 3, same process, us per tick, one launch per pass | pairs of 2-cascade batches): 1024^2 x 8 115.1 | 113.3; the full-size
-    // batches stay where they fit (x 4: 54.5 against 56.7 in half-size batches; x 6: 85.3 | 85.0).
-    for (int cap = (int)(pair_texels / pl); cap >= 1; cap /= 2) {
-        const int B = (count + cap - 1) / cap;
-        bool family_ok = true;
-        for (int b = 0, left = count; b < B; ++b) {
-            sizes[b] = (left + (B - b) - 1) / (B - b);
-            left -= sizes[b];
-            family_ok = family_ok && ow::kernel_family(c->n, sizes[b], c->kernel_mode) == 3;
-        }
-        if (!family_ok) return 0;  // (smaller batches would leave the compact family as well)
-        // spectra: h0 8 + omega 4 B/texel; compact intermediate: 20 B/texel, two batches deep
-        const size_t spectra = 12 * pl * count, batch = 20 * pl * sizes[0];
-        // (2048^2: one cascade per batch is the only shape k_tick_pair_c_split has, and nothing but the intermediate is resident there anyway)
-        if (c->n <= 1024 && !c->pair_full_batches && B > 1 && spectra + batch <= kPairResidentBytes && spectra + 2 * batch > kPairResidentBytes) continue;
-        return B;
+    // Equal batches of at most pair_texels.  (Round 3 halved the batches where two full-size ones next to the spectra overflow the Infinity
+    // Cache -- 1024^2 x 8 as four batches of two: 115 -> 113 us per tick in tick-major order.  With the stream in cascade-major order, below,
+    // a batch only shares the cache with ITSELF one tick later, and full-size batches win: 108.4 -> 104.9; profiles/r04_pairs_order_1024.txt.)
+    const int cap = std::max(1, (int)(pair_texels / pl)), B = (count + cap - 1) / cap;
+    for (int b = 0, left = count; b < B; ++b) {
+        sizes[b] = (left + (B - b) - 1) / (B - b);
+        left -= sizes[b];
+        if (ow::kernel_family(c->n, sizes[b], c->kernel_mode) != 3) return 0;
     }
-    return 0;
+    return B;
 }
 // ticks per launch of a run of `count` cascades in tick groups: four; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick)
 // -- deeper groups pay only there; never more than fits kGroupScratchBytes twice over (the intermediates are double-buffered)
@@ -180,7 +166,6 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
     // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
     // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
-    c->pair_full_batches = getenv("OW_DEBUG_PAIR_FULL") != nullptr;
     c->pair_tick_block = 0;
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));  // measurement knob: 1 = tick-major
     c->pair_texels = kPairTexels;
@@ -835,14 +820,17 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
 // slots in the order ow_update_all takes them), launch i = [pass 2 of batch i - 1 + pass 1 of batch i]; batch i's intermediate lives in
 // scratch slots (i mod 2) * pair_slots ...
 // ORDER OF THE STREAM.  Cascades are independent and a batch's ticks only have to follow each other, so any interleaving of the batches'
-// tick sequences leaves the same bits behind.  Tick-major (all batches of tick t, then tick t + 1) is the default.  At 2048^2 (one cascade
-// per batch, 48 MB of spectra and 16 MB of foam each) a tick of two or more cascades streams more than the 256 MiB Infinity Cache holds
-// next to the two intermediates, so tick-major order re-reads EVERYTHING from DRAM every tick; the stream goes CASCADE-major in blocks of
-// kPairTickBlock ticks instead -- cascade 0 through 64 ticks, then cascade 1 through the same 64, ... -- and 63 launches out of 64 find
-// their spectra (read by the previous launch), their foam (written by it) and their intermediate in the cache, exactly like a one-cascade
-// run.  Measured (profiles/r04_2048_pairs.txt, us per tick, one launch per pass | pairs tick-major | cascade-major in blocks of 8 | of 64):
-// 2048^2 x 2 123.8 | 140.2 | 119.6 | 117.2;  x 4 260.7 | 275.2 | 243.1 | 235.5;  x 8 554.9 | 520.5 | 481.3 | 471.9 -- bit-identical maps.
-// Only the final state of a run is defined for a caller (ow_run = `frames` ow_update_all calls back to back), and it is the same.
+// tick sequences leaves the same bits behind.  A tick of several batches goes CASCADE-major in blocks of kPairTickBlock ticks: batch 0 through
+// 64 ticks, then batch 1 through the same 64, ... -- every launch pairs pass 2 of a batch with pass 1 of THE SAME batch one tick later, so
+//  * 63 launches out of 64 find their spectra (read by the previous launch), their foam (written by it) and both intermediates in the 256 MiB
+//    Infinity Cache, exactly like a one-batch run -- at 2048^2 (one cascade per batch, 48 MB of spectra + 16 MB of foam each) tick-major order
+//    re-reads everything from DRAM every tick and LOSES to one launch per pass at x 2 .. x 4;
+//  * the two passes of a launch always cover the same number of cascades (1024^2 x 5 = 3 + 2: in tick-major order every launch pairs unequal
+//    batches and the surplus blocks run unpaired).
+// Measured (us per tick, one launch per pass | pairs tick-major | cascade-major x 64; profiles/r04_2048_pairs.txt, r04_pairs_order_1024.txt):
+// 2048^2 x 2 123.8 | 140.2 | 117.2;  x 4 260.7 | 275.2 | 235.5;  x 8 554.9 | 520.5 | 471.9;  1024^2 x 5 76.4 | 75.8 | 68.5;  1024^2 x 8 110.1 |
+// 108.4 (half-size batches) | 104.9 (full-size) -- bit-identical maps.  Only the final state of a run is defined for a caller (ow_run =
+// `frames` ow_update_all calls back to back), and it is the same.
 constexpr int kPairTickBlock = 64;
 void advance_slots(double delta, ow_cascade_params *params, int count, int first_slot, int nslots, float *time_out) {  // launch slot i = cascade count-1-i
     for (int i = first_slot; i < first_slot + nslots; ++i) {
@@ -859,7 +847,7 @@ ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params,
         at += sizes[b];
     }
     // the stream: which batch each launch's pass 1 belongs to
-    const int block = c->pair_tick_block > 0 ? c->pair_tick_block : (ow::kernel_streams_from_dram(c->n) ? kPairTickBlock : 1);
+    const int block = c->pair_tick_block > 0 ? c->pair_tick_block : kPairTickBlock;
     const int D = B > 1 ? std::min(ticks, block) : 1;
     std::vector<uint8_t> order;
     order.reserve((size_t)ticks * B);

@@ -104,9 +104,9 @@ typedef struct ow_config {
  *    by several (k_tick_group_c_lp);
  *  - TICK PAIRS, the compact family (1024^2 x 2 .. 8, 512^2 x 7 .., 2048^2 x 1 .. 8): the run is a stream of batches of at most 4 Mi
  *    texels and one launch does pass 2 of one batch and pass 1 of the next -- the same cascades one tick later, or the tick's other
- *    cascades (k_tick_pair_c; k_tick_pair_c_split at 2048^2, where a batch is one cascade and the stream runs each cascade through a block
- *    of up to 64 ticks before it moves on to the next one, so that its spectra and foam are re-read from the Infinity Cache: cascades are
- *    independent, the state ow_run leaves behind is the same).
+ *    cascades (k_tick_pair_c; k_tick_pair_c_split at 2048^2, where a batch is one cascade).  A tick of several batches runs each batch
+ *    through a block of up to 64 ticks before the stream moves on to the next batch, so that a launch pairs a batch with itself one tick
+ *    later and re-reads its spectra and foam from the Infinity Cache: cascades are independent, the state ow_run leaves behind is the same.
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
  * (Measurement knobs, read by ow_create: the environment variables OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" and OW_DEBUG_TICK_GROUP_P2 =
  * "plain" | "pipe" force one of the two forms of the groups' pass-1 / pass-2 work items; unset, the runtime picks by batch size.  Results

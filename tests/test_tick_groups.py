@@ -64,7 +64,7 @@ def test_tick_groups_equal_one_launch_pair_per_tick(n, ids, frames, forms, monke
 
 @pytest.mark.parametrize("n,ids", [(1024, [1, 2]), (1024, [0, 1, 2]), (1024, [0, 1, 2, 3]), (512, [0, 1, 2, 3, 4, 5, 6, 7]),
                                    (1024, [0, 1, 2, 3, 4]), (1024, [0, 1, 2, 3, 4, 5, 6]),  # two batches per tick: 3 + 2, 4 + 3
-                                   (1024, [0, 1, 2, 3, 4, 5, 6, 7]),  # four batches of two (two of four would not fit the Infinity Cache next to the spectra)
+                                   (1024, [0, 1, 2, 3, 4, 5, 6, 7]),  # two batches of four, the stream cascade-major (each batch through up to 64 ticks before the other)
                                    # 2048^2 (k_tick_pair_c_split, round 4): one cascade per batch; pass 2's 16-wave blocks beside pass-1 blocks that
                                    # hold the two 4-row split-plan items of an 8-row unit, each with its own LDS arrival counter as its barrier
                                    (2048, [1]), (2048, [0, 2]), (2048, [0, 1, 2, 3])])
@@ -92,6 +92,22 @@ def test_tick_pairs_equal_one_launch_per_pass(n, ids, frames):
         gen.sync()
     same_maps(a, b, len(ids))
     assert [x.time for x in pa] == [y.time for y in pb]
+
+
+@pytest.mark.parametrize("n,ids,frames", [(1024, [0, 1, 2, 3, 4], 150), (2048, [0, 1, 2], 70), (1024, [0, 1, 2, 3, 4, 5, 6, 7], 67)])
+def test_cascade_major_stream_equals_one_launch_per_pass_across_block_boundaries(n, ids, frames):
+    """A tick of several batches goes out cascade-major in blocks of 64 ticks (ow_runtime.hip run_tick_pairs): batch 0 through 64 ticks, then
+    batch 1 through the same 64, ...  Runs longer than a block, with a partial last block, unequal batches (3 + 2) and the split-plan kernels,
+    against the same ticks one launch per pass: same bits, same times."""
+    a, pa = make(n, ids, True)
+    b, pb = make(n, ids, False)
+    a.run(UPDATE_DELTA, pa, frames)
+    b.run(UPDATE_DELTA, pb, frames)
+    a.sync(); b.sync()
+    assert a.last_kernel_family() == "tick_pairs_compact" and b.last_kernel_family() == "compact"
+    same_maps(a, b, len(ids))
+    for x, y in zip(pa, pb):
+        assert x.time == y.time and x.foam_grow_rate == y.foam_grow_rate and x.foam_decay_rate == y.foam_decay_rate
 
 
 def test_tick_pairs_keep_the_debug_channels_and_match_the_oracle():
@@ -172,12 +188,12 @@ def test_a_dirty_record_or_a_large_batch_stays_off_the_tick_groups():
         big.sync()
         assert big.last_kernel_family() == "tick_pairs_compact" and big.last_batch_cascades() == 1 and big.tick_group_depth() == 1
         big.free()
-    # 1024^2 x 8: two full batches of intermediate do not fit the Infinity Cache next to the spectra -- the run goes out in pairs of
-    # half-size batches (four batches of two per tick) instead of falling back to one launch per pass
+    # 1024^2 x 8: two full-size batches of four, the stream in cascade-major order (round 3's half-size batches are gone: a batch now shares
+    # the Infinity Cache with itself one tick later, not with the other batch)
     big, pbig = make(1024, list(range(8)), True)
     big.run(UPDATE_DELTA, pbig, 4)
     big.sync()
-    assert big.last_kernel_family() == "tick_pairs_compact" and big.last_batch_cascades() == 2
+    assert big.last_kernel_family() == "tick_pairs_compact" and big.last_batch_cascades() == 4
     big.free()
 
 
