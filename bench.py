@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-unmerged", action="store_true", help="skip the second timed region (one launch per pass) behind roofline.unmerged")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample size in seconds of host work (runs BEFORE the GPU regions, so that the "
                                                                     "GPU is busy for one contiguous stretch afterwards)")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic; "
+                                                                      "the figure of an earlier profiling visit (profiles/pmc_traffic.json) is quoted instead")
     ap.add_argument("--no-references", action="store_true", help="N > 1: skip per_gpu_alone / one_gpu_whole_job (the in-line scaling references)")
     ap.add_argument("--sweep", action="store_true", help="one line per BASELINE configuration, appended to --sweep-out")
     ap.add_argument("--sweep-grid", action="store_true", help="like --sweep, over the whole grid 256^2 .. 2048^2 x {1, 4, 8} cascades")
@@ -119,6 +121,48 @@ def cpu_baseline(n, cascades, seconds):
     g.close()
     return {"value": round(frames * cascades / dt, 3), "unit": "maps/s", "cores": cores, "kind": "port",
             "sample": f"{frames} ticks of {n}^2 x {cascades} cascades (oracle, OpenMP x{cores}, {dt:.1f} s)"}
+
+
+def measure_traffic(n, C, kernel, timeout_s=100):
+    """Memory-side bytes per FULL launch of `kernel`, measured now: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit one: the TCC has
+    four counter slots, MI355X_MICROARCH.md) over scripts/drive.py -- one ordinary tick, then 80 ticks through ow_run, i.e. the launches the timed
+    region consists of -- with --kernel-trace beside the counters and nothing else.  FETCH_SIZE[KB] * 1024 * 2 (gfx950 tallies a 128-byte request
+    as 64, same guide) + WRITE_SIZE[KB] * 1024, summed over the kernel's launches and divided by the full-launch equivalents (a run's first and
+    last merged launch carry one pass each: launches - 1).  Returns (bytes_per_full_launch, detail) or raises."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    if any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process is itself being profiled: no nested rocprofv3")
+    sums, launches = {}, {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ow_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "scripts", "drive.py"),
+                                "--map-size", str(n), "--cascades", str(C), "--frames", "81", "--warmup", "1"],
+                               cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                raise RuntimeError(f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}")
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select name, count(distinct dispatch_id), sum(counter_value) from pmc_events where counter_name = ? group by name", (ctr,)).fetchall()
+            db.close()
+            hit = [(nm, cnt, tot) for nm, cnt, tot in rows if f"::{kernel}<" in nm]
+            if not hit:
+                raise RuntimeError(f"{kernel} not among the profiled kernels: {[nm.split('(')[0][-40:] for nm, _, _ in rows]}")
+            sums[ctr] = sum(t for _, _, t in hit)
+            launches[ctr] = sum(c for _, c, _ in hit)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    full = max(1, launches["FETCH_SIZE"] - 1)
+    nbytes = (sums["FETCH_SIZE"] * 2.0 + sums["WRITE_SIZE"]) * 1024.0 / full
+    return int(round(nbytes)), {"FETCH_SIZE_KB_sum": round(sums["FETCH_SIZE"], 1), "WRITE_SIZE_KB_sum": round(sums["WRITE_SIZE"], 1),
+                                "launches": launches["FETCH_SIZE"], "full_launch_equivalents": full}
 
 
 def pmc_traffic(kernel, n, per_launch):
@@ -570,6 +614,20 @@ def main():
         out = measure(args, torch, dist, world, rank, local_rank, n, C)
         if rank == 0:
             out["gpu_phase_s"] = round(time.perf_counter() - t_gpu0, 2)   # contiguous GPU activity of this configuration (priming .. last region)
+            if world == 1 and not args.no_measure_traffic and not args.sweep:
+                # roofline.traffic measured by THIS run (after the timed work: the profiled child process shares the GPU with nothing)
+                rf = out["roofline"]
+                try:
+                    got, detail = measure_traffic(n, C, rf["kernel"])
+                    rf["traffic"] = got
+                    rf["traffic_source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over scripts/drive.py, 80 ticks "
+                                            "through ow_run; FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch; between the XCD L2s and the "
+                                            "fabric, Infinity-Cache hits included")
+                    rf["traffic_detail"] = detail
+                    rf["traffic_bytes_per_texel"] = round(got / max(1, rf["bytes_per_launch"]) * rf["bytes_per_texel"], 2)
+                    rf["traffic_gbps"] = round(got / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                except Exception as e:  # noqa: BLE001  (the profiling leg must not cost the line: the earlier visit's figure stays, labelled)
+                    rf["traffic_measurement_failed"] = f"{type(e).__name__}: {str(e)[:200]}"
             if cpu is not None:
                 out["cpu_baseline"] = cpu
                 if cpu.get("value"):

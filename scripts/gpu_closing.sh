@@ -8,9 +8,9 @@ timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; tail -c 300 $O/bench_driver_cmd.json; echo
 rm -rf $O/trace $O/trace2048 $O/pmc
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --min-time 0.5) > $O/trace.log 2>&1
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-measure-traffic --min-time 0.5) > $O/trace.log 2>&1
 python scripts/rocprof_summary.py $O/trace $O/kernel_trace_1024x4.txt; head -12 $O/kernel_trace_1024x4.txt | cut -c1-150
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace2048" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --map-size 2048 --steps 300 --warmup 30 --min-time 0.5) > $O/trace2048.log 2>&1
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace2048" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-measure-traffic --map-size 2048 --steps 300 --warmup 30 --min-time 0.5) > $O/trace2048.log 2>&1
 python scripts/rocprof_summary.py $O/trace2048 $O/kernel_trace_2048x4.txt; head -8 $O/kernel_trace_2048x4.txt | cut -c1-150
 # PMC: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace beside them and nothing else
 mkdir -p $O/pmc

@@ -28,7 +28,8 @@ def test_bench_needs_a_gpu_and_says_so():
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,kernel", [((), "k_tick_pair_c"), (("--map-size", "256"), "k_tick_group_c_lp"), (("--map-size", "2048", "--cascades", "1"), "k_tick_pair_c_split")])
 def test_one_json_line_with_the_contract_keys(flags, kernel):
-    r = run_bench("--steps", "40", "--warmup", "5", "--min-time", "0.05", "--cpu-seconds", "1", *flags)
+    # (the headline configuration also measures roofline.traffic itself -- two rocprofv3 --pmc passes; the other two quote the profiling visit's figure)
+    r = run_bench("--steps", "40", "--warmup", "5", "--min-time", "0.05", "--cpu-seconds", "1", *flags, *(() if not flags else ("--no-measure-traffic",)))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -48,6 +49,11 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     assert um["ms_per_step"] >= 0.9 * d["ms_per_step"] and 0.0 < um["frac"] < 0.85 and um["value"] > 0 and len(um["kernels"]) == 2
     assert res["reused_bytes"] == res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"] and res["infinity_cache_bytes"] == 256 << 20
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    if not flags:  # measured by the run itself, and close to the design bytes (72.7 B/texel at the memory side against 72)
+        assert rf["traffic_source"].startswith("measured by this run"), rf.get("traffic_measurement_failed")
+        assert 0.9 < rf["traffic"] / rf["bytes_per_launch"] < 1.15 and rf["traffic_detail"]["full_launch_equivalents"] == 80
+    else:
+        assert rf["traffic"] is None or "NOT measured by this run" in rf["traffic_source"]
     # round 4: the CPU leg runs first, the GPU work is one contiguous stretch and says how long it was
     assert d["timed_region_s"] == d["timed_seconds"] > 0 and d["gpu_phase_s"] > d["timed_region_s"]
     assert d["timed_ticks_per_region"] == 40 and d["regions_per_sync"] == 1 and d["scaling"] == "weak"
