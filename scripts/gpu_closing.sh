@@ -31,4 +31,7 @@ import json
 for l in open("$O/sweep_grid.jsonl"):
     d=json.loads(l); r=d["roofline"]; print(d["config"]["map_size"], d["config"]["cascades_per_gpu"], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["tick"]["frac"], r.get("unmerged",{}).get("ms_per_step"), r.get("unmerged",{}).get("frac"), d.get("cpu_baseline",{}).get("value"))
 PY
-timeout 900 python scripts/fuzz_parity.py 40 401 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt
+timeout 900 python scripts/fuzz_parity.py 60 401 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt
+timeout 900 python scripts/fuzz_parity.py 40 77 --wilder --small > $O/fuzz_wilder.txt 2>&1; tail -2 $O/fuzz_wilder.txt
+# the N > 1 rank code on the one GPU of the box (gloo, both ranks on GPU 0: control flow only, the numbers mean nothing)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --share-gpu > $O/rehearsal_2rank.json 2> $O/rehearsal_2rank.err; tail -c 600 $O/rehearsal_2rank.json
