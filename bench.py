@@ -159,7 +159,8 @@ def measure_traffic(n, C, kernel, timeout_s=100):
             launches[ctr] = sum(c for _, c, _ in hit)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    full = max(1, launches["FETCH_SIZE"] - 1)
+    # (ow_run's merged launches: a run's first and last launch carry one pass each = one full launch between them; other kernels: every launch is full)
+    full = max(1, launches["FETCH_SIZE"] - 1) if kernel.startswith("k_tick_") else max(1, launches["FETCH_SIZE"])
     nbytes = (sums["FETCH_SIZE"] * 2.0 + sums["WRITE_SIZE"]) * 1024.0 / full
     return int(round(nbytes)), {"FETCH_SIZE_KB_sum": round(sums["FETCH_SIZE"], 1), "WRITE_SIZE_KB_sum": round(sums["WRITE_SIZE"], 1),
                                 "launches": launches["FETCH_SIZE"], "full_launch_equivalents": full}
