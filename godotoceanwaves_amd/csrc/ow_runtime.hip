@@ -164,10 +164,11 @@ int tick_group_depth_for(const ow_context *c, int count) {
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
-    // measurement knob: batch size of the tick pairs, in Mi texels.  Read here and nowhere else: the scratch is sized from pair_slots, which
-    // follows from it, and a value that changed between ow_create and ow_run would let the merged launches write past that scratch
+    // measurement knobs, read HERE and nowhere else (ow_create): the order of the stream of tick pairs (1 = tick-major), and their batch size in
+    // Mi texels -- the scratch is sized from pair_slots, which follows from it, and a value that changed between ow_create and ow_run would let
+    // the merged launches write past that scratch
     c->pair_tick_block = 0;
-    if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));  // measurement knob: 1 = tick-major
+    if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));
     c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
@@ -268,8 +269,6 @@ ow_status next_events(ow_context *c, hipEvent_t **out, bool single = false) {
     return OW_OK;
 }
 
-// hipStreamSynchronize + the device status word.  hands_out_maps: the caller is about to give map bytes to its caller (everything
-// but a bare ow_sync), which stays refused after a consumed failure until the maps have been recomputed.
 // the status word, consumed: marks what the faulted batches left behind (shared by sync_stream and ow::poll_status)
 ow_status consume_status(ow_context *c) {
     if (!c->status_host || *c->status_host == 0u) {
