@@ -1541,9 +1541,8 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
 // as k_pass1c / k_pass2c: results are bit-identical to one launch per pass.  g.slots2 / g.slots1 = 0 at the two ends of a run.
 // (Measured, MI355X, us per tick against k_pass1c + k_pass2c: 1024^2 x 2 27.6 / 38.5, x 3 42.4 / 50.6, x 4 53.4 / 57.1, 512^2 x 8 27.1 / 34.8.
 //  Deeper groups -- a block walking through 2 or 4 ticks of its columns as in k_tick_group_c_lp -- gain nothing more here and lose
-//  once the deeper scratch leaves the Infinity Cache.  A 2048^2 form (k_pass2c's 16-wave blocks with k_pass1c_split's) was built and
-//  gained 3 % at x 4; the 4-row split blocks gain 8 % and need a different block size than pass 2: N <= 1024 only.
-//  profiles/r02_tick_pairs_compact.txt)
+//  once the deeper scratch leaves the Infinity Cache (profiles/r02_tick_pairs_compact.txt).  N <= 1024: at 2048^2 the two passes'
+//  blocks are of another shape, k_tick_pair_c_split above.)
 template <int N, bool F32>
 __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, FrameArgs args, TickGroupArgs g) {
     static_assert(!plan_row_spans_waves(N), "N <= 1024");
