@@ -395,6 +395,28 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             gen.free()
         except Exception as e:  # noqa: BLE001
             unmerged, unmerged_error = None, f"{type(e).__name__}: {e}"
+    # ---- and as a tick-by-tick caller of ow_update_all gets them (OW_FLAG_RUN_AS_CALLS: ow_run issues one ow_update_all per tick, no merging
+    #      across the run; ow_update_all's own adaptive look-ahead -- a speculated pass 1 of the next tick once the deltas repeat -- stays on) ----
+    calls = calls_error = calls_hits = None
+    if world == 1 and not args.no_unmerged:
+        try:
+            gen = WaveGenerator()
+            gen.map_size, gen.device_id, gen.stream, gen.run_as_calls = n, local_rank, compute.cuda_stream, True
+            gen.external_maps = (disp.data_ptr(), norm.data_ptr())
+            gen.init_gpu(layers)
+            params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
+            disp.zero_()
+            torch.cuda.synchronize()
+            gen.update_all(UPDATE_DELTA, params)
+            gen.run(UPDATE_DELTA, params, max(50, args.warmup))
+            gen.sync()
+            h0 = gen.lookahead_stats()[0]
+            calls, calls_samples = timed(0)
+            calls_hits = (gen.lookahead_stats()[0] - h0) / max(1, len(calls_samples) * state["ticks"])
+            assert bool(torch.isfinite(disp[:C].float()).all()) and float(disp[:C].float().abs().max()) > 0.0
+            gen.free()
+        except Exception as e:  # noqa: BLE001
+            calls, calls_error = None, f"{type(e).__name__}: {e}"
     if rank != 0:
         return None
 
@@ -517,6 +539,12 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
                                          "k_pass2" + SUFFIX[family]:
                                              {"avg_ms_events": round(p2_ms, 5), "frac": round(gbps(k2 * n * n * (C / pairs_per_tick), p2_ms) / HBM_PEAK_GBPS, 4)}}}}
                if unmerged is not None else ({"unmerged": {"error": unmerged_error}} if unmerged_error else {})),
+            **({"update_all_calls": {"launches": "one ow_update_all per tick (OW_FLAG_RUN_AS_CALLS): the tick-by-tick caller, with ow_update_all's adaptive look-ahead "
+                                                 "(a speculated pass 1 of the next tick rides with pass 2 once two deltas in a row were equal)",
+                                     "ms_per_step": round(calls / ticks * 1e3, 5), "value": round(maps / calls, 2), "unit": "maps/s",
+                                     "lookahead_hit_rate": round(calls_hits, 4),
+                                     "frac": round(gbps((k1 + k2) * n * n * C, calls / ticks * 1e3) / HBM_PEAK_GBPS, 4)}}
+               if calls is not None else ({"update_all_calls": {"error": calls_error}} if calls_error else {})),
             "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
                      "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},

@@ -75,6 +75,19 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
+    // ow_update_all's adaptive look-ahead (lookahead_tick below): a pass 1 of the NEXT tick, speculated with the caller's last delta
+    struct Lookahead {
+        bool armed = false;            // the scratch holds a speculated pass 1 that nothing has disturbed since
+        int count = 0, mode = 0;       // cascades of the speculated tick; 1 = compact family (pair kernel), 2 = layer-parallel compact family (group kernel)
+        int base = 0;                  // first scratch slot of the speculated intermediate
+        float time[OW_MAX_CASCADES] = {}, tile_x[OW_MAX_CASCADES] = {}, tile_y[OW_MAX_CASCADES] = {};  // what it was computed with, per launch slot
+        double last_delta = -1.0;      // the previous ow_update_all's delta, and for how many calls in a row it has been the same
+        int streak = 0;
+        uint64_t hits = 0, speculated = 0;
+        bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
+    } la;
+    bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
+    bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
@@ -219,6 +232,7 @@ ow_status ensure_scratch(ow_context *c, int slots) {
     c->buf.pcol = pcol;
     c->buf.rrow = rrow;
     c->scratch_slots = slots;
+    c->la.armed = false;                 // (a speculated pass 1 went with the old buffer, too)
     for (int &sl : c->slot_of) sl = -1;  // (the reference-layout view of the last batch's intermediate went with the old buffer)
     return OW_OK;
 }
@@ -363,8 +377,22 @@ void record_frame_constants(ow_context *c, int cascade, const ow_cascade_params 
 }
 
 // _update() for a batch of cascade indices (wave_generator.gd:65-85)
+ow::CascadeFrame frame_of(const ow_cascade_params &p, int cascade) {
+    ow::CascadeFrame cf;
+    std::memset(&cf, 0, sizeof(cf));
+    cf.tile_x = p.tile_length[0];
+    cf.tile_y = p.tile_length[1];
+    cf.time = (float)p.time;  // push constants are FP32 (render_context.gd:131-134)
+    cf.whitecap = (float)p.whitecap;
+    cf.foam_grow_rate = (float)p.foam_grow_rate;
+    cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
+    cf.cascade = cascade;
+    return cf;
+}
+
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
+    c->la.armed = false;  // this path uses the scratch intermediate from slot 0 on: a speculated pass 1 (lookahead_tick) does not survive it
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     // everything is validated before anything is launched: a bad record must not leave the batch half enqueued
@@ -403,14 +431,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
             w[8] = f32_word(pc.depth), w[9] = f32_word(pc.swell), w[10] = f32_word(pc.detail), w[11] = f32_word(pc.spread), w[12] = (uint32_t)idx[i];
         }
         record_frame_constants(c, idx[i], p);
-        ow::CascadeFrame &cf = args.c[i];
-        cf.tile_x = p.tile_length[0];
-        cf.tile_y = p.tile_length[1];
-        cf.time = (float)p.time;  // push constants are FP32 (render_context.gd:131-134)
-        cf.whitecap = (float)p.whitecap;
-        cf.foam_grow_rate = (float)p.foam_grow_rate;
-        cf.foam_decay = expf(-(float)p.foam_decay_rate);  // fft_unpack.glsl:62, uniform over the dispatch
-        cf.cascade = idx[i];
+        args.c[i] = frame_of(p, idx[i]);
     }
     // Launch in batches of batch_size() cascades (see there).  Cascades are independent, so batching does not change any result.
     const int per_batch = batch_size(c, count);
@@ -437,6 +458,107 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t2));  // rows + unpack (:82-85)
     }
     return OW_OK;
+}
+
+// ---- ow_update_all's adaptive look-ahead ------------------------------------------------------------------------------------------
+// ow_run knows the ticks to come and merges launches across them (tick groups, tick pairs).  A caller that issues ow_update_all tick by tick
+// -- the reference's schedule in throughput form -- gives the runtime no such knowledge, but a regular one is predictable: pass 1 of a tick
+// depends on nothing but the spectra, the tile lengths and the FP32 time, and the time of the next tick is this tick's plus the next delta.
+// So once TWO consecutive calls have come with the same delta, ow_update_all launches pass 2 of its tick together with a SPECULATED pass 1 of
+// the next one (time + delta; the pair / group kernels of ow_run with one tick per side) into the other half of the scratch intermediate.
+// The next call checks the speculation against what it was actually given -- cascade count, every slot's FP32 time and tile lengths, bit for
+// bit; no spectrum to regenerate; nothing else has used the scratch since -- and on a hit its pass 1 is already there: the tick costs one
+// merged launch instead of two (1024^2 x 4: 57.4 -> 53.5 us, 256^2 x 4: 15.4 -> 11.2).  On a miss the speculated work is discarded and the
+// tick takes the ordinary two launches; a caller whose deltas jitter (water.gd's rate limiter passes the elapsed time) never arms it.  Results
+// are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
+// two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
+int lookahead_mode(const ow_context *c, int count) {
+    if (c->no_merge || c->timing || c->inject_fault) return 0;
+    const int fam = ow::kernel_family(c->n, count, c->kernel_mode);
+    int sizes[OW_MAX_CASCADES];
+    if (fam == 3 && c->pair_slots > 0 && pair_batches(c, count, sizes) == 1) return 1;
+    if (fam == 4 && ow::tick_groups_supported(c->n) && count <= c->group_max_count) return 2;
+    return 0;
+}
+// returns true if the tick has been launched here (status in *out); false: the caller takes the ordinary path
+bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
+    ow_context::Lookahead &la = c->la;
+    la.streak = (delta == la.last_delta) ? la.streak + 1 : 0;
+    la.last_delta = delta;
+    const int mode = lookahead_mode(c, count);
+    bool eligible = mode != 0 && std::isfinite(delta);
+    for (int i = 0; eligible && i < count; ++i) eligible = !c->pass_parameters[i].should_generate_spectrum && validate_record(c->pass_parameters[i], i) == OW_OK;
+    // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
+    bool hit = la.armed && eligible && la.count == count && la.mode == mode;
+    for (int i = 0; hit && i < count; ++i) {
+        const ow_cascade_params &p = c->pass_parameters[count - 1 - i];
+        const float t = (float)p.time;
+        hit = std::memcmp(&t, &la.time[i], 4) == 0 && p.tile_length[0] == la.tile_x[i] && p.tile_length[1] == la.tile_y[i];
+    }
+    const int stride = mode == 1 ? c->pair_slots : count;
+    bool speculate = eligible && la.streak >= 1 && !la.hold;
+    if (speculate && ensure_scratch(c, 2 * stride) != OW_OK) speculate = false;  // (growing the scratch disarms: checked before `hit` is used)
+    hit = hit && la.armed;
+    if (!hit && !speculate) {
+        la.armed = false;
+        return false;
+    }
+    ow::FrameArgs args;
+    std::memset(&args, 0, sizeof(args));
+    for (int i = 0; i < count; ++i) {
+        const int cascade = count - 1 - i;
+        const ow_cascade_params &p = c->pass_parameters[cascade];
+        c->maps_faulted &= ~(1u << cascade);
+        c->enqueued_since_sync |= 1u << cascade;
+        record_frame_constants(c, cascade, p);
+        args.c[i] = frame_of(p, cascade);
+    }
+    c->last_args = args;
+    c->last_count = count;
+    c->last_family = ow::kernel_family(c->n, count, c->kernel_mode);
+    for (int &sl : c->slot_of) sl = -1;
+    auto launched = [&](hipError_t e) {
+        if (e == hipSuccess) return true;
+        la.armed = false;
+        *out = fail(OW_ERR_HIP, "look-ahead launch failed: %s", hipGetErrorString(e));
+        return false;
+    };
+    int cur = la.base;
+    if (!hit) {  // this tick's pass 1 has to be computed now: the ordinary launch, scratch slots 0 ..
+        cur = 0;
+        if (!launched(ow::launch_pass1(c->n, count, c->kernel_mode, args, c->buf, c->stream))) return true;
+    } else {
+        ++la.hits;
+    }
+    const int next = cur == 0 ? stride : 0;
+    ow::TickGroupArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    for (int i = 0; speculate && i < count; ++i) {
+        const ow_cascade_params &p = c->pass_parameters[count - 1 - i];
+        la.time[i] = ga.time1[0][i] = (float)(p.time + delta);  // what the next ow_update will make of it (wave_generator.gd:103), narrowed by the pack
+        la.tile_x[i] = p.tile_length[0];
+        la.tile_y[i] = p.tile_length[1];
+    }
+    ga.tbase2[0] = cur;
+    ga.tbase1[0] = next;
+    ga.d2 = 1;
+    ga.d1 = speculate ? 1 : 0;
+    if (mode == 1) {
+        ga.pair_compact = 1;
+        ga.slots2 = count;
+        ga.slots1 = speculate ? count : 0;
+    } else {
+        ga.slots = count;
+        ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
+    }
+    if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
+    la.armed = speculate;
+    la.count = count;
+    la.mode = mode;
+    la.base = next;
+    la.speculated += speculate ? 1 : 0;
+    *out = OW_OK;
+    return true;
 }
 
 ow_status check_cascade(const ow_context *c, int cascade) {
@@ -535,6 +657,8 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     OW_ALLOC(c->buf.omega, L * pl * sizeof(float));
     // scratch between pass 1 and pass 2 of one batch (half of the reference's fft_buffer, :33): one batch worth only, so it
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
+    c->no_merge = (cfg->flags & OW_FLAG_NO_TICK_GROUPS) != 0;
+    c->run_as_calls = (cfg->flags & OW_FLAG_RUN_AS_CALLS) != 0;
     plan_tick_groups(c, cfg->flags);
     if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
@@ -685,9 +809,16 @@ ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, 
     if (st != OW_OK) return st;
     int idx[OW_MAX_CASCADES];
     for (int i = 0; i < count; ++i) idx[i] = count - 1 - i;  // same order _process would take
-    st = enqueue(c, c->pass_parameters, idx, count);
+    if (!lookahead_tick(c, delta, count, &st)) st = enqueue(c, c->pass_parameters, idx, count);
     if (st != OW_OK) return st;
     c->pass_num_cascades_remaining = 0;
+    return OW_OK;
+}
+
+ow_status ow_lookahead_stats(const ow_context *c, uint64_t *hits, uint64_t *speculated) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (hits) *hits = c->la.hits;
+    if (speculated) *speculated = c->la.speculated;
     return OW_OK;
 }
 
@@ -773,6 +904,7 @@ void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_para
 // `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
 //   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
 ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D) {
+    c->la.armed = false;  // (the run uses the whole scratch its own way)
     const int groups = (ticks + D - 1) / D;
     auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
     auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
@@ -839,6 +971,7 @@ void advance_slots(double delta, ow_cascade_params *params, int count, int first
     }
 }
 ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
+    c->la.armed = false;  // (the run uses the whole scratch its own way)
     int sizes[OW_MAX_CASCADES], first[OW_MAX_CASCADES];
     const int B = pair_batches(c, count, sizes);
     for (int b = 0, at = 0; b < B; ++b) {
@@ -896,12 +1029,14 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     int f = 0;
     // the first tick always takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
     if (frames >= 1) {
+        c->la.hold = frames >= 3 && !c->run_as_calls && !c->no_merge;  // (the run's own merged launches take over from tick 2 on)
         ow_status st = ow_update_all(c, delta, params, count);
+        c->la.hold = false;
         if (st != OW_OK) return st;
         f = 1;
     }
     // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
-    int depth = frames - f >= 2 && std::isfinite(delta) ? tick_groups_usable(c, params, count) : 0;
+    int depth = frames - f >= 2 && std::isfinite(delta) && !c->run_as_calls ? tick_groups_usable(c, params, count) : 0;
     if (depth != 0) {
         OW_HIP(hipSetDevice(c->device));
         // the merged launches keep several ticks of intermediate in flight; if that scratch cannot be had the run is not lost: it goes
@@ -1262,6 +1397,7 @@ ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (reps < 1 || c->last_count < 1) return fail(OW_ERR_STATE, "nothing has been launched yet (or reps < 1)");
     OW_HIP(hipSetDevice(c->device));
+    c->la.armed = false;  // (the probe launches write the scratch intermediate from slot 0 on)
     hipEvent_t e[3] = {};
     float a = 0, b = 0;
     auto run = [&]() -> ow_status {

@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_COMPACT, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, OW_FLAG_NO_TICK_GROUPS,
+from ._lib import (OW_FLAG_DEBUG_F32, OW_FLAG_KERNELS_COMPACT, OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, OW_FLAG_NO_TICK_GROUPS, OW_FLAG_RUN_AS_CALLS,
                    ow_cascade_params, ow_config)
 
 G = 9.81       # wave_generator.gd:5
@@ -102,6 +102,7 @@ class WaveGenerator:
         self.debug_f32 = False
         self.kernels = None           # None = runtime picks per batch; "standard" / "layer_parallel" pin the kernel family
         self.tick_groups = True        # False: run() keeps one pair of launches per tick (OW_FLAG_NO_TICK_GROUPS)
+        self.run_as_calls = False      # True: run() issues its ticks as update_all() calls, one per tick (OW_FLAG_RUN_AS_CALLS)
         self.device_id = -1
         self.stream = None
         self.external_maps = (None, None)  # optional caller-owned device buffers (displacement, normal)
@@ -118,7 +119,7 @@ class WaveGenerator:
             self.free()
         cfg = ow_config(map_size=int(self.map_size), num_cascades=int(num_cascades), device_id=self.device_id,
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
-                        normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) | (0 if self.tick_groups else OW_FLAG_NO_TICK_GROUPS) |
+                        normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) | (0 if self.tick_groups else OW_FLAG_NO_TICK_GROUPS) | (OW_FLAG_RUN_AS_CALLS if self.run_as_calls else 0) |
                         {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL,
                                "compact": OW_FLAG_KERNELS_COMPACT,
                                "layer_parallel_compact": OW_FLAG_KERNELS_LAYER_PARALLEL | OW_FLAG_KERNELS_COMPACT}[self.kernels])
@@ -291,6 +292,12 @@ class WaveGenerator:
         """ticks per launch: of the most recent run() that went out in tick groups / tick pairs, else the depth planned for this
         context's small batches (0: no tick groups)"""
         return int(self._lib.ow_tick_group_depth(self.context))
+
+    def lookahead_stats(self):
+        """(hits, speculated): update_all() ticks whose pass 1 had been speculated by the previous call, and speculations launched"""
+        h, sp = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.ow_lookahead_stats(self.context, C.byref(h), C.byref(sp)))
+        return h.value, sp.value
 
     def timing(self, enable):
         """False / 0: off; True / 1: per pass (run() stays on one launch per pass); 2: as launched (tick groups / pairs stay on and are

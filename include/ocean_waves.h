@@ -113,6 +113,9 @@ typedef struct ow_config {
  * in Mi texels, OW_DEBUG_PAIR_TICK_BLOCK = ticks a batch runs through before the stream moves on (1 = tick-major); unset, the runtime's own
  * choices.  Results do not depend on them.) */
 #define OW_FLAG_NO_TICK_GROUPS 16u
+/* ow_run issues its ticks exactly as an external caller of ow_update_all would, one call per tick (no merging across the ticks of the run);
+ * ow_update_all's own adaptive look-ahead stays on.  For measuring what tick-by-tick callers get without a host round trip per tick. */
+#define OW_FLAG_RUN_AS_CALLS 32u
 
 typedef struct ow_context ow_context;
 
@@ -159,8 +162,14 @@ ow_status ow_get_cascade_params(const ow_context *ctx, int32_t index, ow_cascade
 ow_status ow_process(ow_context *ctx);
 
 /* Throughput mode: ow_update() followed by all armed cascades in ONE pair of kernel launches
- * (results identical to calling ow_process() `count` times). */
+ * (results identical to calling ow_process() `count` times).
+ * Adaptive look-ahead: once two consecutive calls have come with the same delta, the call also launches a SPECULATED pass 1 of the next tick
+ * (this tick's times + delta) together with its own pass 2; the next call checks the speculation against what it is actually given (count,
+ * every FP32 time and tile length bit for bit, no spectrum to regenerate, nothing else has run in between) and, on a hit, costs one merged
+ * launch instead of two.  A miss discards the speculated work; results are bit-identical either way.  Single-batch ticks of the compact
+ * families only (map_size >= 256; up to 4 Mi texels per tick); off under OW_FLAG_NO_TICK_GROUPS.  ow_lookahead_stats counts hits. */
 ow_status ow_update_all(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
+ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *speculated);
 
 /* `frames` consecutive ow_update_all() ticks with the same delta, enqueued back to back (the reference's
  * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times. */

@@ -48,6 +48,9 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     um, res = rf["unmerged"], rf["residency"]
     assert um["ms_per_step"] >= 0.9 * d["ms_per_step"] and 0.0 < um["frac"] < 0.85 and um["value"] > 0 and len(um["kernels"]) == 2
     assert res["reused_bytes"] == res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"] and res["infinity_cache_bytes"] == 256 << 20
+    # ... and the tick-by-tick caller of ow_update_all (one call per tick, its adaptive look-ahead on): between the two
+    uc = rf["update_all_calls"]
+    assert uc["lookahead_hit_rate"] > 0.9 and 0.0 < uc["frac"] < 0.85 and uc["ms_per_step"] <= 1.05 * um["ms_per_step"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     if not flags:  # measured by the run itself, and close to the design bytes (72.7 B/texel at the memory side against 72)
         assert rf["traffic_source"].startswith("measured by this run"), rf.get("traffic_measurement_failed")

@@ -1,0 +1,147 @@
+"""ow_update_all's adaptive look-ahead (include/ocean_waves.h): once two consecutive calls have come with the same delta, a call launches a
+SPECULATED pass 1 of the next tick together with its own pass 2, and the next call -- if what it is given matches the speculation bit for
+bit -- costs one merged launch instead of two.  Whatever happens (hits, misses, edits, other calls in between), the maps are BITWISE those
+of a context that never merges anything (OW_FLAG_NO_TICK_GROUPS), tick by tick."""
+import numpy as np
+import pytest
+
+import helpers as H
+from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator
+from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, ids, merge=True, debug=False, run_as_calls=False):
+    gen = WaveGenerator()
+    gen.map_size, gen.tick_groups, gen.debug_f32, gen.run_as_calls = n, merge, debug, run_as_calls
+    gen.init_gpu(max(2, len(ids)))
+    return gen, [WaveCascadeParameters(**cascade_preset(ci)) for ci in ids]
+
+
+def same(a, b, count):
+    a.sync(); b.sync()
+    for i in range(count):
+        da, na = a.get_maps(i)
+        db, nb = b.get_maps(i)
+        assert np.array_equal(da.view(np.uint16), db.view(np.uint16)), i
+        assert np.array_equal(na.view(np.uint16), nb.view(np.uint16)), i
+
+
+@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3]), (256, [0, 1, 2, 3]), (2048, [1]), (512, [0, 1, 2, 3, 4, 5, 6, 7]), (1024, [2]), (1024, [0, 2])])
+def test_regular_cadence_hits_and_equals_one_launch_per_pass(n, ids):
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+    for k in range(12):
+        a.update_all(UPDATE_DELTA, pa)
+        b.update_all(UPDATE_DELTA, pb)
+        if k in (2, 7):
+            same(a, b, len(ids))   # reading the maps in between does not disturb the speculation
+    same(a, b, len(ids))
+    hits, spec = a.lookahead_stats()
+    assert spec == 11 and hits == 10   # call 1: nothing; call 2: speculates (its own pass 1 was not speculated); calls 3 .. 12: hits
+    assert b.lookahead_stats() == (0, 0)
+    assert [p.time for p in pa] == [p.time for p in pb]
+    assert a.last_kernel_family() == b.last_kernel_family()
+
+
+def test_jittering_deltas_never_arm_it_and_a_changed_delta_is_a_miss():
+    n, ids = 1024, [0, 1, 2]
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+    for k in range(8):   # water.gd's rate limiter passes the elapsed time: no two deltas alike
+        d = UPDATE_DELTA * (1.0 + 0.01 * k)
+        a.update_all(d, pa); b.update_all(d, pb)
+    same(a, b, 3)
+    assert a.lookahead_stats() == (0, 0)
+    # 0.02 x 3: -, speculate, hit + speculate; 0.05 x 3: miss (the speculated time is wrong), speculate, hit + speculate; 0.02: miss
+    for d in (0.02, 0.02, 0.02, 0.05, 0.05, 0.05, 0.02):
+        a.update_all(d, pa); b.update_all(d, pb)
+    same(a, b, 3)
+    hits, spec = a.lookahead_stats()
+    assert hits == 2 and spec == 4
+
+
+def test_everything_that_invalidates_a_speculation():
+    n, ids = 512, [0, 1, 2, 3, 4, 5, 6, 7]
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+
+    def both(f):
+        f(a, pa); f(b, pb)
+
+    tick = lambda g, p: g.update_all(UPDATE_DELTA, p)
+    for _ in range(4):
+        both(tick)
+    h0 = a.lookahead_stats()[0]
+    assert h0 == 2
+    # a tile length edited between two calls (pass 1 depends on it): the dirty flag sends the tick down the ordinary path
+    def edit_tile(g, p):
+        p[3].tile_length = (41.0, 43.0)
+    both(edit_tile); both(tick); both(tick); both(tick)
+    # a parameter pass 1 does NOT depend on, edited without the dirty flag (the C caller's way): still a hit, pass 2 sees the new value
+    def edit_whitecap(g, p):
+        p[1]._whitecap = 0.9
+    both(edit_whitecap); both(tick)
+    # fewer cascades, the reference's schedule in between, a run, a restored foam state
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
+    def reference_schedule(g, p):
+        g.update(UPDATE_DELTA, p)
+        for _ in range(3):
+            g._process(0.0)
+    both(reference_schedule); both(tick); both(tick); both(tick)
+    both(lambda g, p: g.run(UPDATE_DELTA, p, 7)); both(tick); both(tick)
+    saved = a.get_maps(2)[1].copy()
+    both(lambda g, p: g.set_normal_map(2, saved)); both(tick); both(tick)
+    same(a, b, len(ids))
+    assert [p.time for p in pa] == [p.time for p in pb]
+    assert a.lookahead_stats()[0] > h0 + 4
+
+
+def test_two_batch_ticks_and_pinned_families_stay_on_the_ordinary_path():
+    a, pa = make(1024, [0, 1, 2, 3, 4])          # 3 + 2: a second batch would need its own two intermediates
+    for _ in range(5):
+        a.update_all(UPDATE_DELTA, pa)
+    a.sync()
+    assert a.lookahead_stats() == (0, 0)
+    g = WaveGenerator()
+    g.map_size, g.kernels = 512, "standard"        # the four-layer kernels have no merged form
+    g.init_gpu(2)
+    p = [WaveCascadeParameters(**cascade_preset(i)) for i in range(2)]
+    for _ in range(5):
+        g.update_all(UPDATE_DELTA, p)
+    g.sync()
+    assert g.lookahead_stats() == (0, 0) and g.last_kernel_family() == "standard"
+
+
+def test_run_as_calls_is_the_tick_by_tick_caller_without_the_host_round_trips():
+    n, ids = 1024, [0, 1, 2, 3]
+    a, pa = make(n, ids, run_as_calls=True)
+    b, pb = make(n, ids, merge=False)
+    a.run(UPDATE_DELTA, pa, 40); b.run(UPDATE_DELTA, pb, 40)
+    same(a, b, 4)
+    hits, spec = a.lookahead_stats()
+    assert hits == 38 and spec == 39 and a.last_kernel_family() == "compact"
+
+
+def test_ticks_through_the_look_ahead_match_the_oracle():
+    n, ids = 1024, [0, 2]
+    gen, params = make(n, ids, debug=True)
+    og = H.oracle_generator(n, ids)
+    for _ in range(5):
+        gen.update_all(UPDATE_DELTA, params)
+        og.update_all(UPDATE_DELTA)
+    gen.sync()
+    assert gen.lookahead_stats()[0] == 3
+    for i in range(2):
+        assert params[i].time == og.params[i].time
+        f32, ref = gen.get_maps_f32(i), og.f32(i)
+        for c, name in enumerate(H.CHANNELS):
+            if name == "foam":
+                assert np.abs(f32[..., c] - ref[..., c]).max() <= H.TOL_FOAM_ABS, (i, name)
+            else:
+                assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
+        disp, norm = gen.get_maps(i)
+        assert H.quantisation_exact(f32, disp, norm)
