@@ -468,7 +468,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
 // the next one (time + delta; the pair / group kernels of ow_run with one tick per side) into the other half of the scratch intermediate.
 // The next call checks the speculation against what it was actually given -- cascade count, every slot's FP32 time and tile lengths, bit for
 // bit; no spectrum to regenerate; nothing else has used the scratch since -- and on a hit its pass 1 is already there: the tick costs one
-// merged launch instead of two (1024^2 x 4: 57.4 -> 53.5 us, 256^2 x 4: 15.4 -> 11.2).  On a miss the speculated work is discarded and the
+// merged launch instead of two (1024^2 x 4: 58.0 -> 54.3 us, 1024^2 x 2: 39.0 -> 28.4, 256^2 x 4: 15.3 -> 11.1, 512^2 x 1: 15.6 -> 11.4).  On a miss the speculated work is discarded and the
 // tick takes the ordinary two launches; a caller whose deltas jitter (water.gd's rate limiter passes the elapsed time) never arms it.  Results
 // are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
 // two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
@@ -549,7 +549,10 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
         ga.slots1 = speculate ? count : 0;
     } else {
         ga.slots = count;
-        ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : (c->n >= 512 || (size_t)count * c->n * c->n >= ((size_t)384 << 10));
+        // pass-1 items in the layer-parallel form: with ONE tick per side the launch is as empty as a lone tick, where more and smaller blocks win
+        // (measured, us per tick, one launch per pass | look-ahead with lp items | with k_pass1c-shaped items: 256^2 x 4 15.3 | 11.1 | 15.9;
+        // 512^2 x 1 15.6 | 11.4 | 17.0; 512^2 x 4 27.3 | 26.2 | 28.4; 1024^2 x 1 29.9 | 25.8 | 28.1; profiles/r04_lookahead.txt)
+        ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : 0;
     }
     if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
     la.armed = speculate;
