@@ -645,7 +645,8 @@ struct TickGroupArgs {
     int32_t slots, n2, n1, d2, d1;
     int32_t pair_compact;            // k_tick_pair_c instead: the compact family's bodies, one batch of each pass --
     int32_t first2, slots2;          //   pass 2 of launch slots first2 .. first2 + slots2 - 1 (scratch slots tbase2[0] ...; slots2 = 0: none)
-    int32_t first1, slots1;          //   pass 1 of launch slots first1 .. first1 + slots1 - 1 (scratch slots tbase1[0] ..., times time1[0][slot])
+    int32_t first1, slots1;          //   pass 1 of launch slots first1 .. first1 + slots1 - 1 (scratch slots tbase1[0] ..., times time1[0][slot]);
+                                     //   the group kernel honours first1 as well: its pass-1 items take launch slots first1 .. first1 + slots - 1
     int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };

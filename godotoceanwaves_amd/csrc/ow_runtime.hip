@@ -80,7 +80,8 @@ struct ow_context {
         bool armed = false;            // the scratch holds a speculated pass 1 that nothing has disturbed since
         int count = 0, mode = 0;       // cascades of the speculated tick; 1 = compact family (pair kernel), 2 = layer-parallel compact family (group kernel)
         int base = 0;                  // first scratch slot of the speculated intermediate
-        float time[OW_MAX_CASCADES] = {}, tile_x[OW_MAX_CASCADES] = {}, tile_y[OW_MAX_CASCADES] = {};  // what it was computed with, per launch slot
+        int cascade[OW_MAX_CASCADES] = {};  // which cascades, per launch slot of the launch that will use it, and
+        float time[OW_MAX_CASCADES] = {}, tile_x[OW_MAX_CASCADES] = {}, tile_y[OW_MAX_CASCADES] = {};  // what their pass 1 was computed with
         double last_delta = -1.0;      // the previous ow_update_all's delta, and for how many calls in a row it has been the same
         int streak = 0;
         uint64_t hits = 0, speculated = 0;
@@ -472,6 +473,9 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
 // tick takes the ordinary two launches; a caller whose deltas jitter (water.gd's rate limiter passes the elapsed time) never arms it.  Results
 // are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
 // two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
+// The reference's own schedule gets the same without any guessing: ow_process of cascade i KNOWS the cascade the next ow_process will
+// take (i - 1, armed with its record), so its launch carries pass 2 of i and pass 1 of i - 1; only the step from an update's last cascade
+// to the next update's first one is a speculation (time + the last delta, once the deltas repeat).
 int lookahead_mode(const ow_context *c, int count) {
     if (c->no_merge || c->timing || c->inject_fault) return 0;
     const int fam = ow::kernel_family(c->n, count, c->kernel_mode);
@@ -480,40 +484,58 @@ int lookahead_mode(const ow_context *c, int count) {
     if (fam == 4 && ow::tick_groups_supported(c->n) && count <= c->group_max_count) return 2;
     return 0;
 }
-// returns true if the tick has been launched here (status in *out); false: the caller takes the ordinary path
-bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
+// What a caller wants launched: pass 2 of `now_count` cascades (launch-slot order) and, ahead of time, pass 1 of `next_count` cascades (0, or
+// as many as now) at the FP32 times they WILL be processed with -- KNOWN where the cascades are armed (ow_process: the next cascade of the same
+// update), SPECULATED where they belong to a tick the caller has not issued yet (time + the caller's last delta).
+struct LookaheadPlan {
+    int now[OW_MAX_CASCADES], now_count;
+    int next[OW_MAX_CASCADES], next_count;
+    float next_time[OW_MAX_CASCADES];
+};
+// returns true if the launch has been made here (status in *out); false: the caller takes the ordinary path
+bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     ow_context::Lookahead &la = c->la;
-    la.streak = (delta == la.last_delta) ? la.streak + 1 : 0;
-    la.last_delta = delta;
-    const int mode = lookahead_mode(c, count);
-    bool eligible = mode != 0 && std::isfinite(delta);
-    for (int i = 0; eligible && i < count; ++i) eligible = !c->pass_parameters[i].should_generate_spectrum && validate_record(c->pass_parameters[i], i) == OW_OK;
-    // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
+    const int count = pl.now_count, mode = lookahead_mode(c, count);
+    bool eligible = mode != 0;
+    for (int i = 0; eligible && i < count; ++i) {
+        const ow_cascade_params &p = c->pass_parameters[pl.now[i]];
+        eligible = !p.should_generate_spectrum && validate_record(p, pl.now[i]) == OW_OK;
+    }
     bool hit = la.armed && eligible && la.count == count && la.mode == mode;
     for (int i = 0; hit && i < count; ++i) {
-        const ow_cascade_params &p = c->pass_parameters[count - 1 - i];
+        const ow_cascade_params &p = c->pass_parameters[pl.now[i]];
         const float t = (float)p.time;
-        hit = std::memcmp(&t, &la.time[i], 4) == 0 && p.tile_length[0] == la.tile_x[i] && p.tile_length[1] == la.tile_y[i];
+        hit = la.cascade[i] == pl.now[i] && std::memcmp(&t, &la.time[i], 4) == 0 && p.tile_length[0] == la.tile_x[i] && p.tile_length[1] == la.tile_y[i];
     }
+    // the launch slots of the cascades computed ahead: the very slots of `now` where they are the same cascades (the next tick of an
+    // ow_update_all), slots of their own behind them otherwise (the next cascade of an ow_process chain)
+    bool ahead = eligible && pl.next_count == count && !la.hold;
+    bool same = ahead;
+    for (int i = 0; ahead && i < count; ++i) {
+        const ow_cascade_params &p = c->pass_parameters[pl.next[i]];
+        ahead = !p.should_generate_spectrum && validate_record(p, pl.next[i]) == OW_OK && std::isfinite(pl.next_time[i]);
+        same = same && pl.next[i] == pl.now[i];
+    }
+    const int first1 = same ? 0 : count;
+    if (ahead && first1 + count > OW_MAX_CASCADES) ahead = false;
     const int stride = mode == 1 ? c->pair_slots : count;
-    bool speculate = eligible && la.streak >= 1 && !la.hold;
-    if (speculate && ensure_scratch(c, 2 * stride) != OW_OK) speculate = false;  // (growing the scratch disarms: checked before `hit` is used)
+    if (ahead && ensure_scratch(c, 2 * stride) != OW_OK) ahead = false;  // (growing the scratch disarms: checked before `hit` is used)
     hit = hit && la.armed;
-    if (!hit && !speculate) {
+    if (!hit && !ahead) {
         la.armed = false;
         return false;
     }
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     for (int i = 0; i < count; ++i) {
-        const int cascade = count - 1 - i;
+        const int cascade = pl.now[i];
         const ow_cascade_params &p = c->pass_parameters[cascade];
         c->maps_faulted &= ~(1u << cascade);
         c->enqueued_since_sync |= 1u << cascade;
         record_frame_constants(c, cascade, p);
         args.c[i] = frame_of(p, cascade);
     }
-    c->last_args = args;
+    c->last_args = args;  // (the probe relaunches THIS tick's cascades)
     c->last_count = count;
     c->last_family = ow::kernel_family(c->n, count, c->kernel_mode);
     for (int &sl : c->slot_of) sl = -1;
@@ -524,7 +546,7 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
         return false;
     };
     int cur = la.base;
-    if (!hit) {  // this tick's pass 1 has to be computed now: the ordinary launch, scratch slots 0 ..
+    if (!hit) {  // this launch's own pass 1 has to be computed now: the ordinary launch, scratch slots 0 ..
         cur = 0;
         if (!launched(ow::launch_pass1(c->n, count, c->kernel_mode, args, c->buf, c->stream))) return true;
     } else {
@@ -533,20 +555,23 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
     const int next = cur == 0 ? stride : 0;
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
-    for (int i = 0; speculate && i < count; ++i) {
-        const ow_cascade_params &p = c->pass_parameters[count - 1 - i];
-        la.time[i] = ga.time1[0][i] = (float)(p.time + delta);  // what the next ow_update will make of it (wave_generator.gd:103), narrowed by the pack
+    for (int i = 0; ahead && i < count; ++i) {
+        const ow_cascade_params &p = c->pass_parameters[pl.next[i]];
+        if (!same) args.c[first1 + i] = frame_of(p, pl.next[i]);  // (pass 1 takes the tile lengths and the layer from it; the time from time1)
+        la.cascade[i] = pl.next[i];
+        la.time[i] = ga.time1[0][first1 + i] = pl.next_time[i];
         la.tile_x[i] = p.tile_length[0];
         la.tile_y[i] = p.tile_length[1];
     }
     ga.tbase2[0] = cur;
     ga.tbase1[0] = next;
     ga.d2 = 1;
-    ga.d1 = speculate ? 1 : 0;
+    ga.d1 = ahead ? 1 : 0;
+    ga.first1 = first1;
     if (mode == 1) {
         ga.pair_compact = 1;
         ga.slots2 = count;
-        ga.slots1 = speculate ? count : 0;
+        ga.slots1 = ahead ? count : 0;
     } else {
         ga.slots = count;
         // pass-1 items in the layer-parallel form: with ONE tick per side the launch is as empty as a lone tick, where more and smaller blocks win
@@ -555,13 +580,44 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
         ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : 0;
     }
     if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
-    la.armed = speculate;
+    la.armed = ahead;
     la.count = count;
     la.mode = mode;
     la.base = next;
-    la.speculated += speculate ? 1 : 0;
+    la.speculated += ahead ? 1 : 0;
     *out = OW_OK;
     return true;
+}
+// ow_update_all: this tick's cascades now, the same cascades one tick later ahead -- once the caller's deltas repeat
+bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
+    LookaheadPlan pl;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.now_count = count;
+    const bool speculate = c->la.streak >= 1 && std::isfinite(delta);
+    pl.next_count = speculate ? count : 0;
+    for (int i = 0; i < count; ++i) {  // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
+        pl.now[i] = pl.next[i] = count - 1 - i;
+        pl.next_time[i] = (float)(c->pass_parameters[count - 1 - i].time + delta);  // what the next ow_update will make of it (wave_generator.gd:103), narrowed by the pack
+    }
+    return lookahead_launch(c, pl, out);
+}
+// ow_process of armed cascade `idx`: ahead goes the cascade the NEXT ow_process will take -- idx - 1 with its armed record (known, not
+// guessed), or, behind the update's last cascade, the first cascade of the next update at time + delta once the caller's deltas repeat
+bool lookahead_process(ow_context *c, int idx, ow_status *out) {
+    LookaheadPlan pl;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.now_count = 1;
+    pl.now[0] = idx;
+    if (idx > 0) {
+        pl.next_count = 1;
+        pl.next[0] = idx - 1;
+        pl.next_time[0] = (float)c->pass_parameters[idx - 1].time;
+    } else if (c->la.streak >= 1 && c->pass_count >= 1) {
+        pl.next_count = 1;
+        pl.next[0] = c->pass_count - 1;
+        pl.next_time[0] = (float)(c->pass_parameters[c->pass_count - 1].time + c->la.last_delta);
+    }
+    return lookahead_launch(c, pl, out);
 }
 
 ow_status check_cascade(const ow_context *c, int cascade) {
@@ -767,6 +823,8 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
         ow_status st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
+    c->la.streak = (delta == c->la.last_delta) ? c->la.streak + 1 : 0;  // the caller's cadence (look-ahead: lookahead_tick / lookahead_process)
+    c->la.last_delta = delta;
     for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
         ow_cascade_params &p = params[i];
         p.time += delta;
@@ -801,7 +859,8 @@ ow_status ow_process(ow_context *c) {  // :56-63
     if (c->pass_num_cascades_remaining == 0) return OW_OK;
     OW_HIP(hipSetDevice(c->device));
     const int idx = c->pass_num_cascades_remaining - 1;
-    ow_status st = enqueue(c, c->pass_parameters, &idx, 1);
+    ow_status st = OW_OK;
+    if (!lookahead_process(c, idx, &st)) st = enqueue(c, c->pass_parameters, &idx, 1);
     if (st != OW_OK) return st;               // a cascade that could not be enqueued stays armed
     c->pass_num_cascades_remaining -= 1;
     return OW_OK;

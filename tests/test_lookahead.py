@@ -145,3 +145,49 @@ def test_ticks_through_the_look_ahead_match_the_oracle():
                 assert H.relmax(f32[..., c], ref[..., c]) < H.TOL_F32, (i, name)
         disp, norm = gen.get_maps(i)
         assert H.quantisation_exact(f32, disp, norm)
+
+
+@pytest.mark.parametrize("n,count", [(1024, 4), (256, 4), (2048, 2), (512, 3)])
+def test_the_reference_schedule_prefetches_the_next_armed_cascade(n, count):
+    """ow_update + one ow_process per frame (wave_generator.gd:56-63,90-109): the launch of cascade i carries pass 1 of cascade i - 1, whose armed
+    record is KNOWN; only the step to the next update's first cascade is a guess (time + delta, once the deltas repeat).  Bitwise the maps of a
+    context that never merges, and every ow_process after the first of the second update is a hit."""
+    ids = list(range(count))
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+    updates = 6
+    for _ in range(updates):
+        for g, p in ((a, pa), (b, pb)):
+            g.update(UPDATE_DELTA, p)
+            while g.pass_num_cascades_remaining:
+                g._process(0.0)
+    same(a, b, count)
+    hits, spec = a.lookahead_stats()
+    # update 1: every spectrum is generated (ordinary path); update 2: count - 1 hits; updates 3 ..: count hits each
+    assert hits == (count - 1) + (updates - 2) * count and spec == hits + 1
+    assert [p.time for p in pa] == [p.time for p in pb]
+
+
+def test_reference_schedule_with_jitter_live_edits_and_leftovers():
+    n, ids = 512, [0, 1, 2, 3]
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+
+    def drive(g, p):
+        for k in range(9):
+            g.update(UPDATE_DELTA * (1.0 + 0.003 * (k % 3)), p)          # no two updates in a row alike: no guess across updates
+            drain = 4 if k % 4 != 2 else 2                               # every fourth update leaves two cascades for the next update's flush
+            for j in range(drain):
+                if k == 5 and j == 1:
+                    p[2].tile_length = (33.0, 35.0)                      # a live edit of the cascade that has just been prefetched: dirty -> ordinary path
+                if k == 6 and j == 2:
+                    p[1]._whitecap = 0.7                                  # pass 2 only: the prefetched pass 1 stays valid
+                g._process(0.0)
+        g.update(UPDATE_DELTA, p)
+        while g.pass_num_cascades_remaining:
+            g._process(0.0)
+
+    drive(a, pa); drive(b, pb)
+    same(a, b, 4)
+    assert [p.time for p in pa] == [p.time for p in pb]
+    assert a.lookahead_stats()[0] >= 12
