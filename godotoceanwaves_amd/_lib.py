@@ -15,6 +15,7 @@ OW_FLAG_KERNELS_LAYER_PARALLEL = 4
 OW_FLAG_KERNELS_COMPACT = 8
 OW_FLAG_NO_TICK_GROUPS = 16
 OW_FLAG_RUN_AS_CALLS = 32
+OW_FLAG_RUN_AS_REFERENCE_SCHEDULE = 64
 OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
 
 

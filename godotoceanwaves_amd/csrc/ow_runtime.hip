@@ -88,6 +88,7 @@ struct ow_context {
         bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
     } la;
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
+    bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
     bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
@@ -718,6 +719,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     // is the same <= 128 MiB for every batch and stays in the Infinity Cache
     c->no_merge = (cfg->flags & OW_FLAG_NO_TICK_GROUPS) != 0;
     c->run_as_calls = (cfg->flags & OW_FLAG_RUN_AS_CALLS) != 0;
+    c->run_as_reference = (cfg->flags & OW_FLAG_RUN_AS_REFERENCE_SCHEDULE) != 0;
     plan_tick_groups(c, cfg->flags);
     if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
@@ -1088,6 +1090,14 @@ ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params,
 ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
     if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
     if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+    if (c->run_as_reference) {  // measurement: the reference's own schedule, call by call
+        for (int f = 0; f < frames; ++f) {
+            if (ow_status st = ow_update(c, delta, params, count); st != OW_OK) return st;
+            for (int k = 0; k < count; ++k)
+                if (ow_status st = ow_process(c); st != OW_OK) return st;
+        }
+        return OW_OK;
+    }
     int f = 0;
     // the first tick always takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
     if (frames >= 1) {

@@ -116,6 +116,8 @@ typedef struct ow_config {
 /* ow_run issues its ticks exactly as an external caller of ow_update_all would, one call per tick (no merging across the ticks of the run);
  * ow_update_all's own adaptive look-ahead stays on.  For measuring what tick-by-tick callers get without a host round trip per tick. */
 #define OW_FLAG_RUN_AS_CALLS 32u
+/* ... and as the reference's own schedule: per tick one ow_update and `count` ow_process calls (wave_generator.gd:56-63,90-109). */
+#define OW_FLAG_RUN_AS_REFERENCE_SCHEDULE 64u
 
 typedef struct ow_context ow_context;
 
@@ -158,7 +160,10 @@ ow_status ow_set_cascade_params(ow_context *ctx, int32_t index, const ow_cascade
 ow_status ow_get_cascade_params(const ow_context *ctx, int32_t index, ow_cascade_params *out);
 
 /* WaveGenerator._process (wave_generator.gd:56-63): processes ONE armed cascade (highest index
- * first) -- the reference's one-cascade-per-rendered-frame load balancing.  No-op when nothing is armed. */
+ * first) -- the reference's one-cascade-per-rendered-frame load balancing.  No-op when nothing is armed.
+ * The launch also carries pass 1 of the cascade the NEXT ow_process will take (index - 1: its armed record is known, nothing is
+ * guessed; behind an update's last cascade: the next update's first one at time + delta, once the deltas repeat), checked when that
+ * call comes -- a record edited in between (ow_set_cascade_params) simply takes the ordinary two launches.  Bit-identical results. */
 ow_status ow_process(ow_context *ctx);
 
 /* Throughput mode: ow_update() followed by all armed cascades in ONE pair of kernel launches

@@ -18,6 +18,9 @@ def child(n, c, mode):
     gen.map_size = n
     gen.tick_groups = mode != "nomerge"
     gen.run_as_calls = mode == "calls"
+    gen.run_as_reference = mode in ("reference", "reference_nomerge")
+    if mode == "reference_nomerge":
+        gen.tick_groups = False
     gen.init_gpu(max(2, c))
     params = [WaveCascadeParameters(**cascade_preset(i)) for i in range(c)]
     gen.run(UPDATE_DELTA, params, 2000)
@@ -38,7 +41,8 @@ if __name__ == "__main__":
     cfgs = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(256, 1), (256, 2), (256, 4), (256, 8), (512, 1), (512, 2), (512, 4), (512, 6), (1024, 1), (1024, 2), (1024, 4), (512, 8)]
     for n, c in cfgs:
         row = []
-        for label, mode, p1 in (("one launch per pass", "nomerge", None), ("update_all + look-ahead", "calls", None), ("  pass-1 items lp", "calls", "lp"), ("  pass-1 items compact", "calls", "compact"), ("ow_run", "run", None)):
+        for label, mode, p1 in (("one launch per pass", "nomerge", None), ("update_all + look-ahead", "calls", None), ("  pass-1 items lp", "calls", "lp"), ("  pass-1 items compact", "calls", "compact"), ("ow_run", "run", None),
+                                ("update + one process per cascade, one launch per pass", "reference_nomerge", None), ("  with the prefetch of the next cascade", "reference", None)):
             env = dict(os.environ)
             env.pop("OW_DEBUG_TICK_GROUP_P1", None)
             if p1:

@@ -191,3 +191,17 @@ def test_reference_schedule_with_jitter_live_edits_and_leftovers():
     same(a, b, 4)
     assert [p.time for p in pa] == [p.time for p in pb]
     assert a.lookahead_stats()[0] >= 12
+
+
+def test_run_as_reference_schedule_is_update_plus_one_process_per_cascade():
+    n, ids = 256, [0, 1, 2, 3]
+    a, pa = make(n, ids)
+    a.free()
+    a = WaveGenerator()
+    a.map_size, a.run_as_reference = n, True
+    a.init_gpu(4)
+    b, pb = make(n, ids, merge=False)
+    a.run(UPDATE_DELTA, pa, 30); b.run(UPDATE_DELTA, pb, 30)
+    same(a, b, 4)
+    hits, spec = a.lookahead_stats()
+    assert hits == 3 + 28 * 4 and a.pass_num_cascades_remaining == 0
