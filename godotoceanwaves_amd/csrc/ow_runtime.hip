@@ -519,6 +519,10 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     }
     const int first1 = same ? 0 : count;
     if (ahead && first1 + count > OW_MAX_CASCADES) ahead = false;
+    // 2048^2: pass 1 of ANOTHER cascade beside pass 2 is the tick-major pairing that loses there (two cascades' spectra and intermediates do not
+    // share the Infinity Cache: 126.0 -> 138.1 us per tick of two cascades on the reference's schedule, profiles/r04_lookahead.txt); the same
+    // cascade one tick later is fine (62.5 -> 59.8)
+    if (ahead && !same && c->n >= 2048) ahead = false;
     const int stride = mode == 1 ? c->pair_slots : count;
     if (ahead && ensure_scratch(c, 2 * stride) != OW_OK) ahead = false;  // (growing the scratch disarms: checked before `hit` is used)
     hit = hit && la.armed;

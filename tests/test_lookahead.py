@@ -147,7 +147,23 @@ def test_ticks_through_the_look_ahead_match_the_oracle():
         assert H.quantisation_exact(f32, disp, norm)
 
 
-@pytest.mark.parametrize("n,count", [(1024, 4), (256, 4), (2048, 2), (512, 3)])
+def test_at_2048_only_the_same_cascade_is_computed_ahead():
+    """pass 1 of ANOTHER cascade beside pass 2 loses at 2048^2 (the tick-major pairing): the reference schedule prefetches nothing there, except
+    across updates where the next cascade is the same one (a context of one cascade)"""
+    a, pa = make(2048, [0, 1])
+    b, pb = make(2048, [0, 1], merge=False)
+    one, p1 = make(2048, [2])
+    for _ in range(4):
+        for g, p in ((a, pa), (b, pb), (one, p1)):
+            g.update(UPDATE_DELTA, p)
+            while g.pass_num_cascades_remaining:
+                g._process(0.0)
+    same(a, b, 2)
+    assert a.lookahead_stats() == (0, 0)
+    assert one.lookahead_stats() == (1, 2)   # update 3 arms cascade 0 of update 4 (deltas of updates 2 and 3 alike); update 4 hits
+
+
+@pytest.mark.parametrize("n,count", [(1024, 4), (256, 4), (512, 3)])
 def test_the_reference_schedule_prefetches_the_next_armed_cascade(n, count):
     """ow_update + one ow_process per frame (wave_generator.gd:56-63,90-109): the launch of cascade i carries pass 1 of cascade i - 1, whose armed
     record is KNOWN; only the step to the next update's first cascade is a guess (time + delta, once the deltas repeat).  Bitwise the maps of a
