@@ -160,7 +160,7 @@ def test_at_2048_only_the_same_cascade_is_computed_ahead():
                 g._process(0.0)
     same(a, b, 2)
     assert a.lookahead_stats() == (0, 0)
-    assert one.lookahead_stats() == (1, 2)   # update 3 arms cascade 0 of update 4 (deltas of updates 2 and 3 alike); update 4 hits
+    assert one.lookahead_stats() == (2, 3)   # update 2 (its delta repeats update 1's) computes ahead for update 3; updates 3 and 4 hit
 
 
 @pytest.mark.parametrize("n,count", [(1024, 4), (256, 4), (512, 3)])
