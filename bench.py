@@ -398,10 +398,12 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
     # ---- and as a tick-by-tick caller of ow_update_all gets them (OW_FLAG_RUN_AS_CALLS: ow_run issues one ow_update_all per tick, no merging
     #      across the run; ow_update_all's own adaptive look-ahead -- a speculated pass 1 of the next tick once the deltas repeat -- stays on) ----
     calls = calls_error = calls_hits = None
-    if world == 1 and not args.no_unmerged:
+    refsched = {}
+    for which in (("calls", "reference") if (world == 1 and not args.no_unmerged) else ()):
         try:
             gen = WaveGenerator()
-            gen.map_size, gen.device_id, gen.stream, gen.run_as_calls = n, local_rank, compute.cuda_stream, True
+            gen.map_size, gen.device_id, gen.stream = n, local_rank, compute.cuda_stream
+            gen.run_as_calls, gen.run_as_reference = which == "calls", which == "reference"
             gen.external_maps = (disp.data_ptr(), norm.data_ptr())
             gen.init_gpu(layers)
             params = [WaveCascadeParameters(**cascade_preset(g)) for g in sharding.owned_cascades(rank, world, C)]
@@ -411,12 +413,19 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             gen.run(UPDATE_DELTA, params, max(50, args.warmup))
             gen.sync()
             h0 = gen.lookahead_stats()[0]
-            calls, calls_samples = timed(0)
-            calls_hits = (gen.lookahead_stats()[0] - h0) / max(1, len(calls_samples) * state["ticks"])
+            t_region, t_samples = timed(0)
+            hit_rate = (gen.lookahead_stats()[0] - h0) / max(1, len(t_samples) * state["ticks"] * (C if which == "reference" else 1))
             assert bool(torch.isfinite(disp[:C].float()).all()) and float(disp[:C].float().abs().max()) > 0.0
             gen.free()
+            if which == "calls":
+                calls, calls_samples, calls_hits = t_region, t_samples, hit_rate
+            else:
+                refsched = {"seconds": t_region, "hit_rate": hit_rate}
         except Exception as e:  # noqa: BLE001
-            calls, calls_error = None, f"{type(e).__name__}: {e}"
+            if which == "calls":
+                calls, calls_error = None, f"{type(e).__name__}: {e}"
+            else:
+                refsched = {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
         return None
 
@@ -545,6 +554,12 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
                                      "lookahead_hit_rate": round(calls_hits, 4),
                                      "frac": round(gbps((k1 + k2) * n * n * C, calls / ticks * 1e3) / HBM_PEAK_GBPS, 4)}}
                if calls is not None else ({"update_all_calls": {"error": calls_error}} if calls_error else {})),
+            **({"reference_schedule": ({"launches": "per tick one ow_update and one ow_process per cascade (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE: wave_generator.gd:56-63,90-109 "
+                                                     "call by call); each ow_process carries pass 1 of the next armed cascade",
+                                         "ms_per_step": round(refsched["seconds"] / ticks * 1e3, 5), "value": round(maps / refsched["seconds"], 2), "unit": "maps/s",
+                                         "lookahead_hit_rate": round(refsched["hit_rate"], 4),
+                                         "frac": round(gbps((k1 + k2) * n * n * C, refsched["seconds"] / ticks * 1e3) / HBM_PEAK_GBPS, 4)}
+                                        if "seconds" in refsched else refsched)} if refsched else {}),
             "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
                      "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},
