@@ -647,6 +647,8 @@ struct TickGroupArgs {
     int32_t first2, slots2;          //   pass 2 of launch slots first2 .. first2 + slots2 - 1 (scratch slots tbase2[0] ...; slots2 = 0: none)
     int32_t first1, slots1;          //   pass 1 of launch slots first1 .. first1 + slots1 - 1 (scratch slots tbase1[0] ..., times time1[0][slot]);
                                      //   the group kernel honours first1 as well: its pass-1 items take launch slots first1 .. first1 + slots - 1
+    int32_t step1;                   //   ... plus j * step1 for pass-1 tick j (group kernel only; 0: every tick the same cascades; `slots`: tick j is
+                                     //   ANOTHER set of cascades at the same tick -- the cascades the reference's next ow_process calls will take)
     int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };

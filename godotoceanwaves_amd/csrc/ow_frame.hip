@@ -125,6 +125,7 @@ static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const D
     using TP = TickPlan<N>;
     if (g.pair_compact) return launch_pair_n<N, F32>(args, g, buf, s, lt);
     if (plan_lp_rows(N) < 2) g.p2_pipe = 0;
+    if (g.slots < 1 || g.first1 < 0 || g.step1 < 0 || g.first1 + (g.d1 > 0 ? g.d1 - 1 : 0) * g.step1 + g.slots > kMaxCascades) return hipErrorInvalidValue;
     g.n2 = g.d2 > 0 ? (g.p2_pipe ? TP::items_2_pipe(g.slots) : TP::items_2(g.slots)) : 0;
     g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;

@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
     if (g.p1_compact) {  // (launch-uniform) Q 8-row items side by side, each doing all its layers (k_pass1c's body): no redundant modulation
         int slot, row0;
         TP::decode_compact(item, sub, slot, row0);
-        const CascadeFrame cf = args.c[g.first1 + slot];  // (first1: the pass-1 cascades may sit in launch slots of their own, ow_runtime.hip lookahead_launch)
+        const CascadeFrame cf = args.c[g.first1 + j * g.step1 + slot];  // (first1, step1: the pass-1 cascades may sit in launch slots of their own, ow_runtime.hip lookahead_launch)
         fetch_arguments(buf, cf);
         pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[j][g.first1 + slot], g.tbase1[j] + slot, row0, tau_sub, tw_lds,
                                                  rows_lds + sub * kWgRows * plan_region_cplx(N), rs, [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
     const bool active = TP::decode(item, sub, g.slots, L, slot, row0);
     // (an idle sub-block of a row-0 item still takes part in the table's block barrier; the row-0 path has no other block barrier,
     //  and in the layer paths every sub-block of the block is active)
-    const CascadeFrame cf = args.c[g.first1 + slot];
+    const CascadeFrame cf = args.c[g.first1 + j * g.step1 + slot];
     fetch_arguments(buf, cf);
     if (active) {
         pass1c_lp_item<N, kAuxDefault>(buf, cf, g.time1[j][g.first1 + slot], g.tbase1[j] + slot, row0, L, tau_sub, tw_lds, rows_lds + sub * kWgRows * plan_region_cplx(N),

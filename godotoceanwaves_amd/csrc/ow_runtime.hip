@@ -77,12 +77,16 @@ struct ow_context {
     bool pc_valid[OW_MAX_CASCADES] = {};
     // ow_update_all's adaptive look-ahead (lookahead_tick below): a pass 1 of the NEXT tick, speculated with the caller's last delta
     struct Lookahead {
-        bool armed = false;            // the scratch holds a speculated pass 1 that nothing has disturbed since
-        int count = 0, mode = 0;       // cascades of the speculated tick; 1 = compact family (pair kernel), 2 = layer-parallel compact family (group kernel)
-        int base = 0;                  // first scratch slot of the speculated intermediate
-        int cascade[OW_MAX_CASCADES] = {};  // which cascades, per launch slot of the launch that will use it, and
-        float time[OW_MAX_CASCADES] = {}, tile_x[OW_MAX_CASCADES] = {}, tile_y[OW_MAX_CASCADES] = {};  // what their pass 1 was computed with
-        double last_delta = -1.0;      // the previous ow_update_all's delta, and for how many calls in a row it has been the same
+        static constexpr int kMaxAhead = 4;  // ticks of pass 1 one launch may compute ahead (group kernel; the pair kernel takes one)
+        bool armed = false;            // the scratch holds pass 1 of `queued` ticks that nothing has disturbed since
+        int count = 0, mode = 0;       // cascades per tick; 1 = compact family (pair kernel), 2 = layer-parallel compact family (group kernel)
+        int queued = 0, head = 0;      // ring of ticks computed ahead: entries head, head + 1, .. (mod kMaxAhead)
+        int group[kMaxAhead] = {};     // scratch group (of `stride` launch slots) that holds each entry's intermediate
+        float time[kMaxAhead][OW_MAX_CASCADES] = {};  // the FP32 times each entry was computed with, per launch slot
+        int cascade[kMaxAhead][OW_MAX_CASCADES] = {};  // which cascades (per launch slot of the launch that will use the entry), and
+        float tile_x[kMaxAhead][OW_MAX_CASCADES] = {}, tile_y[kMaxAhead][OW_MAX_CASCADES] = {};  // the tile lengths their pass 1 was computed with
+        int cur_group = 0;             // group that held the most recent launch's own intermediate
+        double last_delta = -1.0;      // the previous ow_update's delta, and for how many calls in a row it has been the same
         int streak = 0;
         uint64_t hits = 0, speculated = 0;
         bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
@@ -90,6 +94,7 @@ struct ow_context {
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
     bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
+    int ahead_depth = 0;      // ticks of pass 1 ow_update_all's look-ahead computes per launch once the deltas keep repeating (OW_DEBUG_LOOKAHEAD_DEPTH, read once)
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
     // ow_run's tick groups (k_tick_group_c_lp): the largest cascade count they serve (0 = not available) and how many ticks go
@@ -183,6 +188,8 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     // Mi texels -- the scratch is sized from pair_slots, which follows from it, and a value that changed between ow_create and ow_run would let
     // the merged launches write past that scratch
     c->pair_tick_block = 0;
+    c->ahead_depth = ow_context::Lookahead::kMaxAhead;
+    if (const char *e = getenv("OW_DEBUG_LOOKAHEAD_DEPTH")) c->ahead_depth = std::max(1, std::min((int)ow_context::Lookahead::kMaxAhead, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));
     c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
@@ -490,43 +497,54 @@ int lookahead_mode(const ow_context *c, int count) {
 // update), SPECULATED where they belong to a tick the caller has not issued yet (time + the caller's last delta).
 struct LookaheadPlan {
     int now[OW_MAX_CASCADES], now_count;
-    int next[OW_MAX_CASCADES], next_count;
-    float next_time[OW_MAX_CASCADES];
+    int next_count;                          // 0, or now_count: cascades per launch computed ahead
+    int ahead_ticks;                         // how many of the caller's next launches may be computed ahead
+    int next[ow_context::Lookahead::kMaxAhead][OW_MAX_CASCADES];  // their cascades: the same ones a tick later each (ow_update_all), or the ones after `now` (ow_process)
+    float next_time[ow_context::Lookahead::kMaxAhead][OW_MAX_CASCADES];
 };
 // returns true if the launch has been made here (status in *out); false: the caller takes the ordinary path
 bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     ow_context::Lookahead &la = c->la;
+    constexpr int kRing = ow_context::Lookahead::kMaxAhead;
     const int count = pl.now_count, mode = lookahead_mode(c, count);
     bool eligible = mode != 0;
     for (int i = 0; eligible && i < count; ++i) {
         const ow_cascade_params &p = c->pass_parameters[pl.now[i]];
         eligible = !p.should_generate_spectrum && validate_record(p, pl.now[i]) == OW_OK;
     }
-    bool hit = la.armed && eligible && la.count == count && la.mode == mode;
+    bool hit = la.armed && la.queued > 0 && eligible && la.count == count && la.mode == mode;
     for (int i = 0; hit && i < count; ++i) {
         const ow_cascade_params &p = c->pass_parameters[pl.now[i]];
         const float t = (float)p.time;
-        hit = la.cascade[i] == pl.now[i] && std::memcmp(&t, &la.time[i], 4) == 0 && p.tile_length[0] == la.tile_x[i] && p.tile_length[1] == la.tile_y[i];
+        hit = la.cascade[la.head][i] == pl.now[i] && std::memcmp(&t, &la.time[la.head][i], 4) == 0 && p.tile_length[0] == la.tile_x[la.head][i] && p.tile_length[1] == la.tile_y[la.head][i];
     }
-    // the launch slots of the cascades computed ahead: the very slots of `now` where they are the same cascades (the next tick of an
-    // ow_update_all), slots of their own behind them otherwise (the next cascade of an ow_process chain)
-    bool ahead = eligible && pl.next_count == count && !la.hold;
+    // the launch slots of the cascades computed ahead: the very slots of `now` where they are the same cascades (the next ticks of an
+    // ow_update_all), slots of their own behind them otherwise (the cascades the next ow_process calls will take)
+    bool ahead = eligible && pl.next_count == count && pl.ahead_ticks >= 1 && !la.hold;
     bool same = ahead;
-    for (int i = 0; ahead && i < count; ++i) {
-        const ow_cascade_params &p = c->pass_parameters[pl.next[i]];
-        ahead = !p.should_generate_spectrum && validate_record(p, pl.next[i]) == OW_OK && std::isfinite(pl.next_time[i]);
-        same = same && pl.next[i] == pl.now[i];
-    }
-    const int first1 = same ? 0 : count;
-    if (ahead && first1 + count > OW_MAX_CASCADES) ahead = false;
+    for (int k = 0; ahead && k < std::min(pl.ahead_ticks, kRing); ++k)
+        for (int i = 0; i < count; ++i) same = same && pl.next[k][i] == pl.now[i];
     // 2048^2: pass 1 of ANOTHER cascade beside pass 2 is the tick-major pairing that loses there (two cascades' spectra and intermediates do not
     // share the Infinity Cache: 126.0 -> 138.1 us per tick of two cascades on the reference's schedule, profiles/r04_lookahead.txt); the same
     // cascade one tick later is fine (62.5 -> 59.8)
     if (ahead && !same && c->n >= 2048) ahead = false;
-    const int stride = mode == 1 ? c->pair_slots : count;
-    if (ahead && ensure_scratch(c, 2 * stride) != OW_OK) ahead = false;  // (growing the scratch disarms: checked before `hit` is used)
+    // how many launches ahead: the group kernel takes several ticks of pass 1 per launch (the following calls then launch pass 2 alone), the pair
+    // kernel one; never beyond what is asked for, what validates, or what fits the launch's eight cascade frames
+    int depth = !ahead ? 0 : std::min(pl.ahead_ticks, mode == 2 ? c->ahead_depth : 1);
+    if (!same) depth = std::min(depth, (OW_MAX_CASCADES - count) / count);
+    for (int k = 0; k < depth; ++k)
+        for (int i = 0; i < count; ++i) {
+            const ow_cascade_params &p = c->pass_parameters[pl.next[k][i]];
+            if (p.should_generate_spectrum || validate_record(p, pl.next[k][i]) != OW_OK || !std::isfinite(pl.next_time[k][i])) depth = k;
+        }
+    ahead = depth >= 1;
+    const int first1 = (ahead && !same) ? count : 0, step1 = first1;
+    const int stride = mode == 1 ? c->pair_slots : count, groups = (mode == 2 ? kRing : 1) + 1;
+    if (ahead && ensure_scratch(c, groups * stride) != OW_OK) ahead = false;  // (growing the scratch disarms: checked before `hit` is used)
     hit = hit && la.armed;
-    if (!hit && !ahead) {
+    if (!hit) la.queued = 0;  // whatever was computed ahead was computed for something else
+    const bool refill = ahead && (hit ? la.queued == 1 : true);  // (a hit that leaves entries queued launches its pass 2 alone)
+    if (!hit && !refill) {
         la.armed = false;
         return false;
     }
@@ -547,81 +565,109 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     auto launched = [&](hipError_t e) {
         if (e == hipSuccess) return true;
         la.armed = false;
+        la.queued = 0;
         *out = fail(OW_ERR_HIP, "look-ahead launch failed: %s", hipGetErrorString(e));
         return false;
     };
-    int cur = la.base;
-    if (!hit) {  // this launch's own pass 1 has to be computed now: the ordinary launch, scratch slots 0 ..
-        cur = 0;
+    int cur = 0;  // scratch group of this launch's own intermediate
+    if (!hit) {   // it has to be computed now: the ordinary launch, scratch slots 0 .. = group 0
         if (!launched(ow::launch_pass1(c->n, count, c->kernel_mode, args, c->buf, c->stream))) return true;
     } else {
         ++la.hits;
+        cur = la.group[la.head];
+        la.head = (la.head + 1) % kRing;
+        --la.queued;
     }
-    const int next = cur == 0 ? stride : 0;
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
-    for (int i = 0; ahead && i < count; ++i) {
-        const ow_cascade_params &p = c->pass_parameters[pl.next[i]];
-        if (!same) args.c[first1 + i] = frame_of(p, pl.next[i]);  // (pass 1 takes the tile lengths and the layer from it; the time from time1)
-        la.cascade[i] = pl.next[i];
-        la.time[i] = ga.time1[0][first1 + i] = pl.next_time[i];
-        la.tile_x[i] = p.tile_length[0];
-        la.tile_y[i] = p.tile_length[1];
+    if (refill) {  // (the queue is empty here: every group but `cur` is free)
+        la.head = 0;
+        for (int k = 0; k < depth; ++k) {
+            la.group[k] = (cur + 1 + k) % groups;
+            ga.tbase1[k] = la.group[k] * stride;
+            for (int i = 0; i < count; ++i) {
+                const ow_cascade_params &p = c->pass_parameters[pl.next[k][i]];
+                if (!same) args.c[first1 + k * step1 + i] = frame_of(p, pl.next[k][i]);  // (pass 1 takes the tile lengths and the layer from it; the times from time1)
+                la.time[k][i] = ga.time1[k][first1 + i] = pl.next_time[k][i];
+                la.cascade[k][i] = pl.next[k][i];
+                la.tile_x[k][i] = p.tile_length[0];
+                la.tile_y[k][i] = p.tile_length[1];
+            }
+        }
+        la.queued = depth;
     }
-    ga.tbase2[0] = cur;
-    ga.tbase1[0] = next;
+    ga.tbase2[0] = cur * stride;
     ga.d2 = 1;
-    ga.d1 = ahead ? 1 : 0;
+    ga.d1 = refill ? depth : 0;
     ga.first1 = first1;
+    ga.step1 = mode == 2 ? step1 : 0;
     if (mode == 1) {
         ga.pair_compact = 1;
         ga.slots2 = count;
-        ga.slots1 = ahead ? count : 0;
+        ga.slots1 = refill ? count : 0;
     } else {
         ga.slots = count;
-        // pass-1 items in the layer-parallel form: with ONE tick per side the launch is as empty as a lone tick, where more and smaller blocks win
-        // (measured, us per tick, one launch per pass | look-ahead with lp items | with k_pass1c-shaped items: 256^2 x 4 15.3 | 11.1 | 15.9;
-        // 512^2 x 1 15.6 | 11.4 | 17.0; 512^2 x 4 27.3 | 26.2 | 28.4; 1024^2 x 1 29.9 | 25.8 | 28.1; profiles/r04_lookahead.txt)
-        ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : 0;
+        // pass-1 items in the layer-parallel form: with ONE tick of pass 2 per launch the launch is as empty as a lone tick, where more and smaller
+        // blocks win (measured, us per tick, one launch per pass | look-ahead with lp items | with k_pass1c-shaped items: 256^2 x 4 15.3 | 11.1 |
+        // 15.9; 512^2 x 1 15.6 | 11.4 | 17.0; 512^2 x 4 27.3 | 26.2 | 28.4; 1024^2 x 1 29.9 | 25.8 | 28.1; profiles/r04_lookahead.txt)
+        // ... and in k_pass1c's form from 512 Ki texels per tick on, where the several ticks of pass 1 of one launch are enough work for the fewer,
+        // larger items (us per tick at four ticks ahead, lp | compact: 256^2 x 4 9.7 | 10.5, 512^2 x 1 10.2 | 11.2, 256^2 x 8 13.3 | 12.2,
+        // 512^2 x 2 13.7 | 12.7, 512^2 x 4 23.9 | 19.7, 1024^2 x 1 23.0 | 19.7; profiles/r04_lookahead_depth.txt)
+        ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)count * depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
     }
     if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
-    la.armed = ahead;
+    la.armed = la.queued > 0;
     la.count = count;
     la.mode = mode;
-    la.base = next;
-    la.speculated += ahead ? 1 : 0;
+    la.cur_group = cur;
+    la.speculated += refill ? 1 : 0;
     *out = OW_OK;
     return true;
 }
-// ow_update_all: this tick's cascades now, the same cascades one tick later ahead -- once the caller's deltas repeat
+// ow_update_all: this tick's cascades now, the same cascades ahead -- one tick once the caller's deltas repeat, several once they keep repeating
 bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
     LookaheadPlan pl;
     std::memset(&pl, 0, sizeof(pl));
     pl.now_count = count;
     const bool speculate = c->la.streak >= 1 && std::isfinite(delta);
     pl.next_count = speculate ? count : 0;
+    pl.ahead_ticks = !speculate ? 0 : (c->la.streak >= 2 ? ow_context::Lookahead::kMaxAhead : 1);
     for (int i = 0; i < count; ++i) {  // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
-        pl.now[i] = pl.next[i] = count - 1 - i;
-        pl.next_time[i] = (float)(c->pass_parameters[count - 1 - i].time + delta);  // what the next ow_update will make of it (wave_generator.gd:103), narrowed by the pack
+        pl.now[i] = count - 1 - i;
+        double t = c->pass_parameters[count - 1 - i].time;
+        for (int k = 0; k < ow_context::Lookahead::kMaxAhead; ++k) {
+            t += delta;  // what the k + 1-th ow_update from now will make of it (wave_generator.gd:103: one FP64 add per update), narrowed by the pack
+            pl.next[k][i] = count - 1 - i;
+            pl.next_time[k][i] = (float)t;
+        }
     }
     return lookahead_launch(c, pl, out);
 }
-// ow_process of armed cascade `idx`: ahead goes the cascade the NEXT ow_process will take -- idx - 1 with its armed record (known, not
-// guessed), or, behind the update's last cascade, the first cascade of the next update at time + delta once the caller's deltas repeat
+// ow_process of armed cascade `idx`: ahead go the cascades the NEXT ow_process calls will take -- idx - 1, idx - 2, .. with their armed records
+// (known, not guessed), or, behind the update's last cascade, the cascades of the next update at time + delta once the caller's deltas repeat
 bool lookahead_process(ow_context *c, int idx, ow_status *out) {
+    constexpr int kMax = ow_context::Lookahead::kMaxAhead;
     LookaheadPlan pl;
     std::memset(&pl, 0, sizeof(pl));
     pl.now_count = 1;
     pl.now[0] = idx;
-    if (idx > 0) {
-        pl.next_count = 1;
-        pl.next[0] = idx - 1;
-        pl.next_time[0] = (float)c->pass_parameters[idx - 1].time;
-    } else if (c->la.streak >= 1 && c->pass_count >= 1) {
-        pl.next_count = 1;
-        pl.next[0] = c->pass_count - 1;
-        pl.next_time[0] = (float)(c->pass_parameters[c->pass_count - 1].time + c->la.last_delta);
+    // the caller's next launches, in order: the armed cascades below idx (known), then -- a guess, once the deltas repeat -- the cascades of the
+    // next update(s) from the top, each at its time + delta (+ delta ...)
+    int k = 0;
+    for (; k < kMax && k < idx; ++k) {
+        pl.next[k][0] = idx - 1 - k;
+        pl.next_time[k][0] = (float)c->pass_parameters[idx - 1 - k].time;
     }
+    const int pc = c->pass_count;
+    for (int j = 0; k < kMax && pc >= 1 && c->la.streak >= (j == 0 ? 1 : 2); ++j, ++k) {
+        const int cascade = pc - 1 - j % pc;
+        double t = c->pass_parameters[cascade].time;
+        for (int r = 0; r <= j / pc; ++r) t += c->la.last_delta;  // (one FP64 add per update, wave_generator.gd:103)
+        pl.next[k][0] = cascade;
+        pl.next_time[k][0] = (float)t;
+    }
+    pl.next_count = k > 0 ? 1 : 0;
+    pl.ahead_ticks = k;
     return lookahead_launch(c, pl, out);
 }
 

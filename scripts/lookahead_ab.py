@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ow_update_all tick by tick (OW_FLAG_RUN_AS_CALLS) with its adaptive look-ahead against one launch per pass (OW_FLAG_NO_TICK_GROUPS), and -- for
-the layer-parallel compact family, whose look-ahead launch is the group kernel with one tick per side -- the two forms of its pass-1 items
-(OW_DEBUG_TICK_GROUP_P1, read by ow_create).  One process per variant.   python scripts/lookahead_ab.py [n:c ...]   us per tick, median of 7 x 400"""
+the layer-parallel compact family, whose look-ahead launch is the group kernel with one tick per side -- how many ticks of pass 1 a launch computes ahead
+(OW_DEBUG_LOOKAHEAD_DEPTH) and the two forms of its pass-1 items (OW_DEBUG_TICK_GROUP_P1), both read by ow_create.  One process per variant.   python scripts/lookahead_ab.py [n:c ...]   us per tick, median of 7 x 400"""
 import os
 import statistics
 import subprocess
@@ -31,7 +31,7 @@ def child(n, c, mode):
         gen.run(UPDATE_DELTA, params, 400)
         gen.sync()
         samples.append((time.perf_counter() - t0) / 400 * 1e6)
-    print(f"{statistics.median(samples):7.2f} (hits {gen.lookahead_stats()[0]})")
+    print(f"{statistics.median(samples):7.2f} (hits {gen.lookahead_stats()[0]}, launches with work ahead {gen.lookahead_stats()[1]})")
 
 
 if __name__ == "__main__":
@@ -41,11 +41,15 @@ if __name__ == "__main__":
     cfgs = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(256, 1), (256, 2), (256, 4), (256, 8), (512, 1), (512, 2), (512, 4), (512, 6), (1024, 1), (1024, 2), (1024, 4), (512, 8)]
     for n, c in cfgs:
         row = []
-        for label, mode, p1 in (("one launch per pass", "nomerge", None), ("update_all + look-ahead", "calls", None), ("  pass-1 items lp", "calls", "lp"), ("  pass-1 items compact", "calls", "compact"), ("ow_run", "run", None),
+        for label, mode, p1 in (("one launch per pass", "nomerge", None), ("update_all + look-ahead", "calls", None), ("  one tick ahead", "calls", "depth1"), ("  two", "calls", "depth2"),
+                                ("  pass-1 items compact", "calls", "compact"), ("ow_run", "run", None),
                                 ("update + one process per cascade, one launch per pass", "reference_nomerge", None), ("  with the prefetch of the next cascade", "reference", None)):
             env = dict(os.environ)
             env.pop("OW_DEBUG_TICK_GROUP_P1", None)
-            if p1:
+            env.pop("OW_DEBUG_LOOKAHEAD_DEPTH", None)
+            if p1 and p1.startswith("depth"):
+                env["OW_DEBUG_LOOKAHEAD_DEPTH"] = p1[5:]
+            elif p1:
                 env["OW_DEBUG_TICK_GROUP_P1"] = p1
             r = subprocess.run([sys.executable, __file__, "--child", str(n), str(c), mode], env=env, capture_output=True, text=True)
             row.append(f"{label}: {r.stdout.strip() or r.stderr.strip()[-200:]}")

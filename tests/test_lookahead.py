@@ -39,14 +39,18 @@ def test_regular_cadence_hits_and_equals_one_launch_per_pass(n, ids):
             same(a, b, len(ids))   # reading the maps in between does not disturb the speculation
     same(a, b, len(ids))
     hits, spec = a.lookahead_stats()
-    assert spec == 11 and hits == 10   # call 1: nothing; call 2: speculates (its own pass 1 was not speculated); calls 3 .. 12: hits
+    assert hits == 10   # call 1: nothing; call 2: computes ahead (its own pass 1 was not); calls 3 .. 12: hits
+    # launches that carried work for later ticks -- the pair kernel one tick per launch: calls 2 .. 12; the group kernel (layer-parallel
+    # family) four ticks per launch once the delta has repeated twice: call 2 (one tick), then calls 3, 7, 11
+    assert spec == (4 if a.last_kernel_family() == "layer_parallel_compact" else 11)
     assert b.lookahead_stats() == (0, 0)
     assert [p.time for p in pa] == [p.time for p in pb]
     assert a.last_kernel_family() == b.last_kernel_family()
 
 
-def test_jittering_deltas_never_arm_it_and_a_changed_delta_is_a_miss():
-    n, ids = 1024, [0, 1, 2]
+@pytest.mark.parametrize("n", [1024, 256])   # (the pair kernel: one tick ahead; the group kernel: up to four)
+def test_jittering_deltas_never_arm_it_and_a_changed_delta_is_a_miss(n):
+    ids = [0, 1, 2]
     a, pa = make(n, ids)
     b, pb = make(n, ids, merge=False)
     for k in range(8):   # water.gd's rate limiter passes the elapsed time: no two deltas alike
@@ -62,8 +66,9 @@ def test_jittering_deltas_never_arm_it_and_a_changed_delta_is_a_miss():
     assert hits == 2 and spec == 4
 
 
-def test_everything_that_invalidates_a_speculation():
-    n, ids = 512, [0, 1, 2, 3, 4, 5, 6, 7]
+@pytest.mark.parametrize("n,ids", [(512, [0, 1, 2, 3, 4, 5, 6, 7]), (256, [0, 1, 2, 3, 4]), (512, [4, 5])])
+def test_everything_that_invalidates_a_speculation(n, ids):
+    """(512^2 x 8: the pair kernel, one tick ahead; the other two: the group kernel, whose queue of up to four ticks is cut short by each event)"""
     a, pa = make(n, ids)
     b, pb = make(n, ids, merge=False)
 
@@ -77,24 +82,28 @@ def test_everything_that_invalidates_a_speculation():
     assert h0 == 2
     # a tile length edited between two calls (pass 1 depends on it): the dirty flag sends the tick down the ordinary path
     def edit_tile(g, p):
-        p[3].tile_length = (41.0, 43.0)
+        p[-1].tile_length = (41.0, 43.0)
     both(edit_tile); both(tick); both(tick); both(tick)
     # a parameter pass 1 does NOT depend on, edited without the dirty flag (the C caller's way): still a hit, pass 2 sees the new value
     def edit_whitecap(g, p):
         p[1]._whitecap = 0.9
     both(edit_whitecap); both(tick)
     # fewer cascades, the reference's schedule in between, a run, a restored foam state
-    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
-    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
-    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:5]))
+    fewer = max(1, len(ids) - 3)
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:fewer]))
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:fewer]))
+    both(lambda g, p: g.update_all(UPDATE_DELTA, p[:fewer]))
     def reference_schedule(g, p):
         g.update(UPDATE_DELTA, p)
-        for _ in range(3):
+        for _ in range(min(3, len(ids))):
             g._process(0.0)
     both(reference_schedule); both(tick); both(tick); both(tick)
     both(lambda g, p: g.run(UPDATE_DELTA, p, 7)); both(tick); both(tick)
-    saved = a.get_maps(2)[1].copy()
-    both(lambda g, p: g.set_normal_map(2, saved)); both(tick); both(tick)
+    saved = a.get_maps(1)[1].copy()
+    both(lambda g, p: g.set_normal_map(1, saved)); both(tick); both(tick)
+    # a changed delta in the middle of a queue of ticks computed ahead, and back
+    for d in (UPDATE_DELTA,) * 4 + (0.03,) * 5 + (UPDATE_DELTA,) * 6:
+        both(lambda g, p: g.update_all(d, p))
     same(a, b, len(ids))
     assert [p.time for p in pa] == [p.time for p in pb]
     assert a.lookahead_stats()[0] > h0 + 4
@@ -180,7 +189,9 @@ def test_the_reference_schedule_prefetches_the_next_armed_cascade(n, count):
     same(a, b, count)
     hits, spec = a.lookahead_stats()
     # update 1: every spectrum is generated (ordinary path); update 2: count - 1 hits; updates 3 ..: count hits each
-    assert hits == (count - 1) + (updates - 2) * count and spec == hits + 1
+    assert hits == (count - 1) + (updates - 2) * count
+    # launches that carried pass 1 for later ones: one in four where a single launch takes the next four of the caller's launches
+    assert hits // 4 <= spec <= hits + 1
     assert [p.time for p in pa] == [p.time for p in pb]
 
 
