@@ -537,7 +537,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
             **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n} if grouped else {}),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
             "residency": res,
-            **({"unmerged": {"launches": "one launch per pass and batch (OW_FLAG_NO_TICK_GROUPS): what ow_update_all / ow_process callers get",
+            **({"unmerged": {"launches": "one launch per pass and batch (OW_FLAG_NO_TICK_GROUPS): what callers with an irregular cadence get",
                              "ms_per_step": round(unmerged / ticks * 1e3, 5), "value": round(maps / unmerged, 2), "unit": "maps/s",
                              "ms_per_step_min_max": [round(min(unmerged_samples) / ticks * 1e3, 5), round(max(unmerged_samples) / ticks * 1e3, 5)],
                              "bytes_per_texel": k1 + k2, "achieved": round(gbps((k1 + k2) * n * n * C, unmerged / ticks * 1e3), 1),
@@ -555,7 +555,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C):
                                      "frac": round(gbps((k1 + k2) * n * n * C, calls / ticks * 1e3) / HBM_PEAK_GBPS, 4)}}
                if calls is not None else ({"update_all_calls": {"error": calls_error}} if calls_error else {})),
             **({"reference_schedule": ({"launches": "per tick one ow_update and one ow_process per cascade (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE: wave_generator.gd:56-63,90-109 "
-                                                     "call by call); each ow_process carries pass 1 of the next armed cascade",
+                                                     "call by call); an ow_process carries pass 1 of up to four of the cascades the next calls will take, which then launch pass 2 alone",
                                          "ms_per_step": round(refsched["seconds"] / ticks * 1e3, 5), "value": round(maps / refsched["seconds"], 2), "unit": "maps/s",
                                          "lookahead_hit_rate": round(refsched["hit_rate"], 4),
                                          "frac": round(gbps((k1 + k2) * n * n * C, refsched["seconds"] / ticks * 1e3) / HBM_PEAK_GBPS, 4)}
