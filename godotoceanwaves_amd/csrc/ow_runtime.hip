@@ -477,13 +477,18 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
 // the next one (time + delta; the pair / group kernels of ow_run with one tick per side) into the other half of the scratch intermediate.
 // The next call checks the speculation against what it was actually given -- cascade count, every slot's FP32 time and tile lengths, bit for
 // bit; no spectrum to regenerate; nothing else has used the scratch since -- and on a hit its pass 1 is already there: the tick costs one
-// merged launch instead of two (1024^2 x 4: 58.0 -> 54.3 us, 1024^2 x 2: 39.0 -> 28.4, 256^2 x 4: 15.3 -> 11.1, 512^2 x 1: 15.6 -> 11.4).  On a miss the speculated work is discarded and the
+// merged launch instead of two (1024^2 x 4: 58.0 -> 54.3 us, 1024^2 x 2: 39.0 -> 28.4).  On a miss the speculated work is discarded and the
 // tick takes the ordinary two launches; a caller whose deltas jitter (water.gd's rate limiter passes the elapsed time) never arms it.  Results
 // are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
 // two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
-// The reference's own schedule gets the same without any guessing: ow_process of cascade i KNOWS the cascade the next ow_process will
-// take (i - 1, armed with its record), so its launch carries pass 2 of i and pass 1 of i - 1; only the step from an update's last cascade
-// to the next update's first one is a speculation (time + the last delta, once the deltas repeat).
+// FOUR AHEAD: where the launch is the group kernel (layer-parallel compact family, ticks of up to 1 Mi texels) and the delta has repeated
+// twice, one launch computes pass 1 of the next four ticks -- a queue of entries, each with its own group of the scratch ring (five groups:
+// the one being read + four) -- and the three calls in between launch pass 2 alone: 256^2 x 4 15.3 -> 9.7 us per tick (11.1 with one tick
+// ahead), 512^2 x 4 26.8 -> 20.2 (26.2), 1024^2 x 1 29.9 -> 20.3 (25.8); nothing more beyond four (profiles/r04_lookahead_depth.txt).
+// The reference's own schedule gets the same without any guessing: ow_process of cascade i KNOWS the cascades the next ow_process calls will
+// take (i - 1, i - 2, .., armed with their records), so its launch carries pass 2 of i and pass 1 of up to four of them (the queue's entries are
+// then different cascades: TickGroupArgs.step1); only the steps into the next update are speculation (time + the last delta, once the deltas
+// repeat).  1024^2 x 4 on that schedule: 119.0 -> 85.3 us per update.
 int lookahead_mode(const ow_context *c, int count) {
     if (c->no_merge || c->timing || c->inject_fault) return 0;
     const int fam = ow::kernel_family(c->n, count, c->kernel_mode);
@@ -492,9 +497,9 @@ int lookahead_mode(const ow_context *c, int count) {
     if (fam == 4 && ow::tick_groups_supported(c->n) && count <= c->group_max_count) return 2;
     return 0;
 }
-// What a caller wants launched: pass 2 of `now_count` cascades (launch-slot order) and, ahead of time, pass 1 of `next_count` cascades (0, or
-// as many as now) at the FP32 times they WILL be processed with -- KNOWN where the cascades are armed (ow_process: the next cascade of the same
-// update), SPECULATED where they belong to a tick the caller has not issued yet (time + the caller's last delta).
+// What a caller wants launched: pass 2 of `now_count` cascades (launch-slot order) and, ahead of time, pass 1 of the cascades its next
+// `ahead_ticks` launches will take at the FP32 times they WILL be processed with -- KNOWN where the cascades are armed (ow_process: the next
+// cascades of the same update), SPECULATED where they belong to a tick the caller has not issued yet (time + the caller's last delta).
 struct LookaheadPlan {
     int now[OW_MAX_CASCADES], now_count;
     int next_count;                          // 0, or now_count: cascades per launch computed ahead
