@@ -1,17 +1,28 @@
 #!/bin/bash
 # closing state of a round: the GPU suite, the default bench line, the rocprofv3 kernel trace of the same command on the same box (and of the
 # 2048^2 x 4 configuration), PMC passes (separate runs, no tracing domains beside them), the sweep over north_star's grid, a slice of the fuzz.
-#   R=r04 bash scripts/gpu_closing.sh
+#   R=r04 bash scripts/gpu_closing.sh          PARTS="bench trace" R=r04 bash scripts/gpu_closing.sh   (a subset: tests bench trace trace2048 pmc sweep fuzz rehearsal)
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=${R:-r04}; O=gpurun_out/${R}_closing; mkdir -p $O; export TMPDIR=/tmp
+PARTS=${PARTS:-tests bench trace trace2048 pmc sweep fuzz rehearsal}
+want() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+if want tests; then
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+fi
+if want bench; then
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; tail -c 300 $O/bench_driver_cmd.json; echo
+fi
 rm -rf $O/trace $O/trace2048 $O/pmc
+if want trace; then
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-measure-traffic --min-time 0.5) > $O/trace.log 2>&1
 python scripts/rocprof_summary.py $O/trace $O/kernel_trace_1024x4.txt; head -12 $O/kernel_trace_1024x4.txt | cut -c1-150
+fi
+if want trace2048; then
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/trace2048" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-measure-traffic --map-size 2048 --steps 300 --warmup 30 --min-time 0.5) > $O/trace2048.log 2>&1
 python scripts/rocprof_summary.py $O/trace2048 $O/kernel_trace_2048x4.txt; head -8 $O/kernel_trace_2048x4.txt | cut -c1-150
+fi
+if want pmc; then
 # PMC: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace beside them and nothing else
 mkdir -p $O/pmc
 for cfg in "1024 4 21" "2048 4 65" "2048 1 21" "1024 8 21" "256 4 81"; do
@@ -24,14 +35,21 @@ for cfg in "1024 4 21" "2048 4 65" "2048 1 21" "1024 8 21" "256 4 81"; do
 done
 python scripts/rocprof_summary.py $O/pmc $O/pmc_fetch_write.txt
 grep -E "^## |FETCH_SIZE|WRITE_SIZE" $O/pmc_fetch_write.txt | grep -E "^## |k_tick|k_pass" | cut -c1-170
+fi
 rm -rf $O/trace $O/trace2048 $O/pmc/*/*.db 2>/dev/null; find $O -name "*.db" -delete
+if want sweep; then
 rm -f $O/sweep_grid.jsonl
 timeout 1800 python bench.py --sweep-grid --steps 500 --warmup 50 --min-time 0.3 --cpu-seconds 3 --prime-ms 300 --sweep-out $O/sweep_grid.jsonl > $O/sweep.log 2>&1; python - <<PY
 import json
 for l in open("$O/sweep_grid.jsonl"):
     d=json.loads(l); r=d["roofline"]; print(d["config"]["map_size"], d["config"]["cascades_per_gpu"], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["tick"]["frac"], r.get("unmerged",{}).get("ms_per_step"), r.get("unmerged",{}).get("frac"), d.get("cpu_baseline",{}).get("value"))
 PY
+fi
+if want fuzz; then
 timeout 900 python scripts/fuzz_parity.py 60 401 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt
 timeout 900 python scripts/fuzz_parity.py 40 77 --wilder --small > $O/fuzz_wilder.txt 2>&1; tail -2 $O/fuzz_wilder.txt
+fi
+if want rehearsal; then
 # the N > 1 rank code on the one GPU of the box (gloo, both ranks on GPU 0: control flow only, the numbers mean nothing)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --share-gpu > $O/rehearsal_2rank.json 2> $O/rehearsal_2rank.err; tail -c 600 $O/rehearsal_2rank.json
+fi
