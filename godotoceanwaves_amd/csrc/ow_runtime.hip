@@ -481,8 +481,8 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
 // tick takes the ordinary two launches; a caller whose deltas jitter (water.gd's rate limiter passes the elapsed time) never arms it.  Results
 // are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
 // two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
-// FOUR AHEAD: where the launch is the group kernel (layer-parallel compact family, ticks of up to 1 Mi texels) and the delta has repeated
-// twice, one launch computes pass 1 of the next four ticks -- a queue of entries, each with its own group of the scratch ring (five groups:
+// FOUR AHEAD: where the launch is the group kernel (layer-parallel compact family, ticks of up to 1 Mi texels), one launch computes pass 1 of
+// as many of the next ticks as the delta has repeated, up to four -- a queue of entries, each with its own group of the scratch ring (five groups:
 // the one being read + four) -- and the three calls in between launch pass 2 alone: 256^2 x 4 15.3 -> 9.7 us per tick (11.1 with one tick
 // ahead), 512^2 x 4 26.8 -> 20.2 (26.2), 1024^2 x 1 29.9 -> 20.3 (25.8); nothing more beyond four (profiles/r04_lookahead_depth.txt).
 // The reference's own schedule gets the same without any guessing: ow_process of cascade i KNOWS the cascades the next ow_process calls will
@@ -636,7 +636,8 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
     pl.now_count = count;
     const bool speculate = c->la.streak >= 1 && std::isfinite(delta);
     pl.next_count = speculate ? count : 0;
-    pl.ahead_ticks = !speculate ? 0 : (c->la.streak >= 2 ? ow_context::Lookahead::kMaxAhead : 1);
+    // as many ticks ahead as the delta has repeated (up to four): what a changed delta throws away never exceeds what the repeats have saved
+    pl.ahead_ticks = !speculate ? 0 : std::min(c->la.streak, (int)ow_context::Lookahead::kMaxAhead);
     for (int i = 0; i < count; ++i) {  // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
         pl.now[i] = count - 1 - i;
         double t = c->pass_parameters[count - 1 - i].time;
@@ -664,7 +665,7 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
         pl.next_time[k][0] = (float)c->pass_parameters[idx - 1 - k].time;
     }
     const int pc = c->pass_count;
-    for (int j = 0; k < kMax && pc >= 1 && c->la.streak >= (j == 0 ? 1 : 2); ++j, ++k) {
+    for (int j = 0; k < kMax && pc >= 1 && j < c->la.streak; ++j, ++k) {  // (as many guesses as the delta has repeated)
         const int cascade = pc - 1 - j % pc;
         double t = c->pass_parameters[cascade].time;
         for (int r = 0; r <= j / pc; ++r) t += c->la.last_delta;  // (one FP64 add per update, wave_generator.gd:103)

@@ -41,7 +41,7 @@ def test_regular_cadence_hits_and_equals_one_launch_per_pass(n, ids):
     hits, spec = a.lookahead_stats()
     assert hits == 10   # call 1: nothing; call 2: computes ahead (its own pass 1 was not); calls 3 .. 12: hits
     # launches that carried work for later ticks -- the pair kernel one tick per launch: calls 2 .. 12; the group kernel (layer-parallel
-    # family) four ticks per launch once the delta has repeated twice: call 2 (one tick), then calls 3, 7, 11
+    # family) as many ticks as the delta has repeated, up to four: call 2 (one tick), call 3 (two), call 5 (four), call 9
     assert spec == (4 if a.last_kernel_family() == "layer_parallel_compact" else 11)
     assert b.lookahead_stats() == (0, 0)
     assert [p.time for p in pa] == [p.time for p in pb]
