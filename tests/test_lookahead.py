@@ -232,3 +232,19 @@ def test_run_as_reference_schedule_is_update_plus_one_process_per_cascade():
     same(a, b, 4)
     hits, spec = a.lookahead_stats()
     assert hits == 3 + 28 * 4 and a.pass_num_cascades_remaining == 0
+
+
+@pytest.mark.parametrize("n,count", [(256, 4), (512, 2), (1024, 1), (512, 8), (2048, 1)])
+def test_random_schedules_hold_the_bits_of_a_context_that_never_merges(n, count):
+    """scripts/fuzz_schedule.py: random sequences of update_all (repeating and changing deltas), update + some or all of its process calls, short
+    runs, live edits, fewer cascades, restored foam -- every merged launch shape against OW_FLAG_NO_TICK_GROUPS, bit for bit"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_schedule", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_schedule.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    served = 0
+    for seed in (11, 12, 13):
+        calls, hits = fz.schedule(n, count, seed, ops=30)
+        served += hits
+    assert served > 0   # (the schedules do reach the look-ahead)
