@@ -94,6 +94,7 @@ struct ow_context {
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
     bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
+    int group_depth_forced = 0;  // OW_DEBUG_TICK_GROUP_DEPTH (measurements; read once)
     int ahead_depth = 0;      // ticks of pass 1 ow_update_all's look-ahead computes per launch once the deltas keep repeating (OW_DEBUG_LOOKAHEAD_DEPTH, read once)
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
@@ -151,9 +152,9 @@ int batch_size(const ow_context *c, int count) {
 
 // ow_run on a batch of the layer-parallel compact family goes out in tick groups (k_tick_group_c_lp), which need the scratch
 // intermediate 2 * depth times.  Largest cascade count served for this context, and the depth that fits kGroupScratchBytes:
-// (with 1 GiB instead -- depth 4 up to 1024^2 x 2 -- nothing changes where it matters: 1024^2 x 2 39.4 vs 39.4 us on k_pass1c + k_pass2c,
-// x 3 62.7 vs 53.2, 512^2 x 6 30.2 vs 30.3)
-constexpr size_t kGroupScratchBytes = (size_t)256 << 20;
+// 512 MiB = four ticks per launch up to 512^2 x 6 (round 4, us per tick at 2 / 3 / 4 / 6 ticks per launch: 512^2 x 5 21.5 / 20.2 / 19.6 / 18.9,
+// x 6 25.3 / 24.6 / 23.0 / 23.3: with 256 MiB these ran at three and two; profiles/r04_group_depth.txt).  A few hundred MiB of a 288 GB part.
+constexpr size_t kGroupScratchBytes = (size_t)512 << 20;
 // Ticks of the compact family go out as tick pairs (k_tick_pair_c / k_tick_pair_c_split: pass 2 of one batch and pass 1 of the next in one
 // launch), in equal batches of at most kPairTexels -- a tick of 1024^2 x 5 .. 8 is two batches (3 + 2, 3 + 3, 4 + 3, 4 + 4), at 2048^2 a batch is
 // one cascade.  The scratch is two batches deep: at 4 Mi texels 160 MiB of intermediate in flight, which the Infinity Cache holds next to the
@@ -175,11 +176,13 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
     }
     return B;
 }
-// ticks per launch of a run of `count` cascades in tick groups: four; eight where a tick is tiny (256^2 x <= 4: 5.9 -> 5.3 us per tick)
-// -- deeper groups pay only there; never more than fits kGroupScratchBytes twice over (the intermediates are double-buffered)
+// ticks per launch of a run of `count` cascades in tick groups: four; eight where a tick is small -- up to 512 Ki texels (256^2 x <= 8,
+// 512^2 x <= 2; us per tick at 4 / 8: 256^2 x 4 5.9 / 5.3 before the pipelined pass 2, x 8 7.79 / 7.28, 512^2 x 2 7.85 / 7.35; from 512^2 x 4
+// and 1024^2 x 1 on four is the best: 14.3 / 15.0, 14.7 / 15.4) -- never more than fits kGroupScratchBytes twice over (double-buffered)
 int tick_group_depth_for(const ow_context *c, int count) {
     const size_t per_tick = (size_t)count * c->n * c->n * ow::kLayers * sizeof(ow::cplx);
-    const size_t cap = per_tick <= ((size_t)8 << 20) ? ow::kMaxTickGroup : 4;
+    const size_t cap = per_tick <= ((size_t)16 << 20) ? ow::kMaxTickGroup : 4;
+    if (c->group_depth_forced > 0) return c->group_depth_forced;
     return (int)std::min<size_t>(cap, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
@@ -188,6 +191,8 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     // Mi texels -- the scratch is sized from pair_slots, which follows from it, and a value that changed between ow_create and ow_run would let
     // the merged launches write past that scratch
     c->pair_tick_block = 0;
+    c->group_depth_forced = 0;
+    if (const char *e = getenv("OW_DEBUG_TICK_GROUP_DEPTH")) c->group_depth_forced = std::max(0, std::min((int)ow::kMaxTickGroup, atoi(e)));
     c->ahead_depth = ow_context::Lookahead::kMaxAhead;
     if (const char *e = getenv("OW_DEBUG_LOOKAHEAD_DEPTH")) c->ahead_depth = std::max(1, std::min((int)ow_context::Lookahead::kMaxAhead, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));

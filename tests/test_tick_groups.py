@@ -222,26 +222,26 @@ def test_tick_groups_interleaved_with_the_reference_schedule_and_changing_counts
 
 
 def test_group_depth_follows_the_run_and_the_scratch_grows_on_first_use():
-    """the depth of a tick group follows the cascade count of THAT run (256^2: eight for up to four cascades, four
-    beyond), not the largest count the context could ever see; and the deeper scratch intermediate the merged launches need is
+    """the depth of a tick group follows the cascade count of THAT run (512^2: eight ticks per launch for up to two
+    cascades, four beyond), not the largest count the context could ever see; and the deeper scratch intermediate the merged launches need is
     allocated by the first ow_run that uses them, mid-stream, without disturbing the simulation (same bits as a context that never
     merges)."""
-    n, ids = 256, list(range(8))
+    n, ids = 512, list(range(6))
     a, pa = make(n, ids, True)
     b, pb = make(n, ids, False)
     for gen, p in ((a, pa), (b, pb)):
         gen.update_all(UPDATE_DELTA, p)              # ordinary ticks first: one batch of scratch
         gen.update(UPDATE_DELTA, p)
         gen._process(0.0)
-    a.run(UPDATE_DELTA, pa[:4], 20)                  # (flushes the leftovers, then the groups: the scratch grows here)
+    a.run(UPDATE_DELTA, pa[:2], 20)                  # (flushes the leftovers, then the groups: the scratch grows here)
     assert a.last_kernel_family() == "tick_groups_compact" and a.tick_group_depth() == 8
     a.run(UPDATE_DELTA, pa, 20)
     assert a.last_kernel_family() == "tick_groups_compact" and a.tick_group_depth() == 4
-    a.run(UPDATE_DELTA, pa[:2], 11)
+    a.run(UPDATE_DELTA, pa[:1], 11)
     assert a.tick_group_depth() == 8
-    b.run(UPDATE_DELTA, pb[:4], 20)
+    b.run(UPDATE_DELTA, pb[:2], 20)
     b.run(UPDATE_DELTA, pb, 20)
-    b.run(UPDATE_DELTA, pb[:2], 11)
+    b.run(UPDATE_DELTA, pb[:1], 11)
     a.sync(); b.sync()
     same_maps(a, b, len(ids))
     assert [x.time for x in pa] == [y.time for y in pb]
