@@ -109,7 +109,7 @@ typedef struct ow_config {
  *    later and re-reads its spectra and foam from the Infinity Cache: cascades are independent, the state ow_run leaves behind is the same.
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
  * (Measurement knobs, read by ow_create: the environment variables OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" and OW_DEBUG_TICK_GROUP_P2 =
- * "plain" | "pipe" force one of the two forms of the groups' pass-1 / pass-2 work items, OW_DEBUG_PAIR_TEXELS = batch size of the tick pairs
+ * "plain" | "pipe" force one of the two forms of the groups' pass-1 / pass-2 work items, OW_DEBUG_TICK_GROUP_DEPTH = ticks per launch of the groups, OW_DEBUG_PAIR_TEXELS = batch size of the tick pairs
  * in Mi texels, OW_DEBUG_PAIR_TICK_BLOCK = ticks a batch runs through before the stream moves on (1 = tick-major), OW_DEBUG_LOOKAHEAD_DEPTH =
  * ticks of pass 1 one ow_update_all computes ahead at most (1 .. 4); unset, the runtime's own
  * choices.  Results do not depend on them.) */
