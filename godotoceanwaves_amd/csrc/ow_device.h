@@ -636,8 +636,8 @@ struct TickPlan {
 };
 
 // one launch of ow_run's tick groups (k_tick_group_c_lp): pass 2 of d2 consecutive ticks and pass 1 of d1 later ticks
-constexpr int kMaxTickGroup = 8;  // (measured: 6 / 8 / 12 ticks per group gain another 8 / 12 / 15 % over 4 at 256^2 x 4 and nothing from 512^2 x 4 on:
-                                  //  the runtime goes to 8 only where a tick is at most 512 Ki texels)
+constexpr int kMaxTickGroup = 16;  // (ticks per launch: four; eight up to 512 Ki texels per tick; twelve / sixteen for the smallest ticks -- the
+                                   //  runtime's rule and its measurements: ow_runtime.hip tick_group_depth_for, profiles/r04_group_depth.txt)
 struct TickGroupArgs {
     float time1[kMaxTickGroup][8];   // FP32-narrowed params.time of the d1 pass-1 ticks, per launch slot
     int32_t tbase2[kMaxTickGroup];   // first scratch slot of each pass-2 tick

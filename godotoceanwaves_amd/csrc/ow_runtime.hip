@@ -181,7 +181,11 @@ int pair_batches(const ow_context *c, int count, int *sizes) {
 // and 1024^2 x 1 on four is the best: 14.3 / 15.0, 14.7 / 15.4) -- never more than fits kGroupScratchBytes twice over (double-buffered)
 int tick_group_depth_for(const ow_context *c, int count) {
     const size_t per_tick = (size_t)count * c->n * c->n * ow::kLayers * sizeof(ow::cplx);
-    const size_t cap = per_tick <= ((size_t)16 << 20) ? ow::kMaxTickGroup : 4;
+    // ... and further where a launch of eight is still mostly fixed costs: sixteen for one or two cascades of up to 256 Ki texels together
+    // (us per tick at 8 / 12 / 16: 256^2 x 1 3.10 / 2.85 / 2.79, x 2 3.17 / 3.03 / 2.97, 512^2 x 1 4.21 / 3.99 / 3.89), twelve for three or
+    // four (256^2 x 4 3.95 / 3.82 / 3.91); 256^2 x 8 stays at eight (7.41 / 7.21)
+    const size_t cap = per_tick <= ((size_t)8 << 20) ? (count <= 2 ? 16 : 12) : per_tick <= ((size_t)16 << 20) ? 8 : 4;
+    static_assert(ow::kMaxTickGroup >= 16, "the deepest tick group has to fit TickGroupArgs");
     if (c->group_depth_forced > 0) return c->group_depth_forced;
     return (int)std::min<size_t>(cap, std::max<size_t>(1, kGroupScratchBytes / (2 * per_tick)));
 }

@@ -132,7 +132,7 @@ def test_tick_pairs_keep_the_debug_channels_and_match_the_oracle():
 
 def test_timing_as_launched_keeps_the_merged_launches():
     """timing mode 2: tick groups / tick pairs stay on and every such launch is timed; mode 1 puts ow_run back on one launch per pass"""
-    for n, ids, fam, depth in ((1024, [0, 1], "tick_pairs_compact", 1), (256, [0, 1, 2, 3], "tick_groups_compact", 8)):
+    for n, ids, fam, depth in ((1024, [0, 1], "tick_pairs_compact", 1), (256, [0, 1, 2, 3], "tick_groups_compact", 12)):
         gen, p = make(n, ids, True)
         gen.timing(2)
         gen.run(UPDATE_DELTA, p, 34)
@@ -222,8 +222,8 @@ def test_tick_groups_interleaved_with_the_reference_schedule_and_changing_counts
 
 
 def test_group_depth_follows_the_run_and_the_scratch_grows_on_first_use():
-    """the depth of a tick group follows the cascade count of THAT run (512^2: eight ticks per launch for up to two
-    cascades, four beyond), not the largest count the context could ever see; and the deeper scratch intermediate the merged launches need is
+    """the depth of a tick group follows the cascade count of THAT run (512^2: sixteen ticks per launch for one cascade,
+    eight for two, four beyond), not the largest count the context could ever see; and the deeper scratch intermediate the merged launches need is
     allocated by the first ow_run that uses them, mid-stream, without disturbing the simulation (same bits as a context that never
     merges)."""
     n, ids = 512, list(range(6))
@@ -238,7 +238,7 @@ def test_group_depth_follows_the_run_and_the_scratch_grows_on_first_use():
     a.run(UPDATE_DELTA, pa, 20)
     assert a.last_kernel_family() == "tick_groups_compact" and a.tick_group_depth() == 4
     a.run(UPDATE_DELTA, pa[:1], 11)
-    assert a.tick_group_depth() == 8
+    assert a.tick_group_depth() == 16
     b.run(UPDATE_DELTA, pb[:2], 20)
     b.run(UPDATE_DELTA, pb, 20)
     b.run(UPDATE_DELTA, pb[:1], 11)
