@@ -88,6 +88,7 @@ struct ow_context {
         int cur_group = 0;             // group that held the most recent launch's own intermediate
         double last_delta = -1.0;      // the previous ow_update's delta, and for how many calls in a row it has been the same
         int streak = 0;
+        int prev_run = 1;              // updates in the caller's previous run of equal deltas (1: none that says anything)
         uint64_t hits = 0, speculated = 0;
         bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
     } la;
@@ -95,6 +96,8 @@ struct ow_context {
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
     bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
     int group_depth_forced = 0;  // OW_DEBUG_TICK_GROUP_DEPTH (measurements; read once)
+    int run_delta_period = 0;    // OW_DEBUG_RUN_DELTA_CHANGE_EVERY: the call-by-call forms of ow_run (OW_FLAG_RUN_AS_CALLS / _AS_REFERENCE_SCHEDULE) switch
+                                 // between delta and 1.25 delta every that many ticks -- an irregular caller for the look-ahead to miss on (measurements)
     int ahead_depth = 0;      // ticks of pass 1 ow_update_all's look-ahead computes per launch once the deltas keep repeating (OW_DEBUG_LOOKAHEAD_DEPTH, read once)
     int pair_tick_block = 0;  // ticks a batch runs through before the stream of tick pairs moves on to the next batch (0: by map size; OW_DEBUG_PAIR_TICK_BLOCK, read once)
     size_t pair_texels = 0;  // batch size of ow_run's tick pairs, in texels (kPairTexels; OW_DEBUG_PAIR_TEXELS is read ONCE, by ow_create)
@@ -196,6 +199,8 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     // the merged launches write past that scratch
     c->pair_tick_block = 0;
     c->group_depth_forced = 0;
+    c->run_delta_period = 0;
+    if (const char *e = getenv("OW_DEBUG_RUN_DELTA_CHANGE_EVERY")) c->run_delta_period = std::max(0, std::min(1 << 20, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_DEPTH")) c->group_depth_forced = std::max(0, std::min((int)ow::kMaxTickGroup, atoi(e)));
     c->ahead_depth = ow_context::Lookahead::kMaxAhead;
     if (const char *e = getenv("OW_DEBUG_LOOKAHEAD_DEPTH")) c->ahead_depth = std::max(1, std::min((int)ow_context::Lookahead::kMaxAhead, atoi(e)));
@@ -491,7 +496,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
 // are bit-identical either way (same item bodies; tests/test_lookahead.py).  Single-batch ticks only: a second batch would need its own
 // two intermediates.  Off under OW_FLAG_NO_TICK_GROUPS, per-launch timing and fault injection.
 // FOUR AHEAD: where the launch is the group kernel (layer-parallel compact family, ticks of up to 1 Mi texels), one launch computes pass 1 of
-// as many of the next ticks as the delta has repeated, up to four -- a queue of entries, each with its own group of the scratch ring (five groups:
+// as many of the next ticks as the caller's cadence predicts (predicted_repeats), up to four -- a queue of entries, each with its own group of the scratch ring (five groups:
 // the one being read + four) -- and the three calls in between launch pass 2 alone: 256^2 x 4 15.3 -> 9.7 us per tick (11.1 with one tick
 // ahead), 512^2 x 4 26.8 -> 20.2 (26.2), 1024^2 x 1 29.9 -> 20.3 (25.8); nothing more beyond four (profiles/r04_lookahead_depth.txt).
 // The reference's own schedule gets the same without any guessing: ow_process of cascade i KNOWS the cascades the next ow_process calls will
@@ -638,15 +643,26 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     *out = OW_OK;
     return true;
 }
+// How many further updates with the same delta the caller's cadence lets one assume.  The delta has repeated `streak` times so far; the
+// caller's PREVIOUS run of equal deltas was prev_run updates long.  Inside a run that the previous one predicts, no further than that one
+// went (a caller whose delta changes every k updates is never speculated across a change: measured before this rule, such callers paid up
+// to 30 % MORE than one launch per pass -- every change threw away up to four ticks of pass 1; profiles/r04_lookahead_misses.txt); beyond
+// it -- and for the first run, prev_run = 1 -- as many as this run has outlasted the prediction by: evidence accumulates anew.
+int predicted_repeats(const ow_context::Lookahead &la) {
+    const int s = la.streak, last = la.prev_run - 1;  // `last`: the streak value at which the previous run ended
+    if (s < 1) return 0;
+    return s < last ? std::min(s, last - s) : s - last;
+}
 // ow_update_all: this tick's cascades now, the same cascades ahead -- one tick once the caller's deltas repeat, several once they keep repeating
 bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
     LookaheadPlan pl;
     std::memset(&pl, 0, sizeof(pl));
     pl.now_count = count;
-    const bool speculate = c->la.streak >= 1 && std::isfinite(delta);
+    const int repeats = std::isfinite(delta) ? predicted_repeats(c->la) : 0;
+    const bool speculate = repeats >= 1;
     pl.next_count = speculate ? count : 0;
-    // as many ticks ahead as the delta has repeated (up to four): what a changed delta throws away never exceeds what the repeats have saved
-    pl.ahead_ticks = !speculate ? 0 : std::min(c->la.streak, (int)ow_context::Lookahead::kMaxAhead);
+    // as many ticks ahead as the caller's cadence predicts (up to four)
+    pl.ahead_ticks = !speculate ? 0 : std::min(repeats, (int)ow_context::Lookahead::kMaxAhead);
     for (int i = 0; i < count; ++i) {  // launch slot i = cascade count - 1 - i, as enqueue() takes them from ow_update_all
         pl.now[i] = count - 1 - i;
         double t = c->pass_parameters[count - 1 - i].time;
@@ -674,7 +690,8 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
         pl.next_time[k][0] = (float)c->pass_parameters[idx - 1 - k].time;
     }
     const int pc = c->pass_count;
-    for (int j = 0; k < kMax && pc >= 1 && j < c->la.streak; ++j, ++k) {  // (as many guesses as the delta has repeated)
+    const int repeats = predicted_repeats(c->la);
+    for (int j = 0; k < kMax && pc >= 1 && j / pc < repeats; ++j, ++k) {  // (update j / pc + 1 from now: only as far as the cadence predicts)
         const int cascade = pc - 1 - j % pc;
         double t = c->pass_parameters[cascade].time;
         for (int r = 0; r <= j / pc; ++r) t += c->la.last_delta;  // (one FP64 add per update, wave_generator.gd:103)
@@ -890,7 +907,12 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
         ow_status st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
-    c->la.streak = (delta == c->la.last_delta) ? c->la.streak + 1 : 0;  // the caller's cadence (look-ahead: lookahead_tick / lookahead_process)
+    if (delta == c->la.last_delta) {  // the caller's cadence (look-ahead: lookahead_tick / lookahead_process)
+        if (c->la.streak < (1 << 30)) ++c->la.streak;
+    } else {
+        c->la.prev_run = c->la.streak + 1;
+        c->la.streak = 0;
+    }
     c->la.last_delta = delta;
     for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
         ow_cascade_params &p = params[i];
@@ -1155,9 +1177,11 @@ ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params,
 ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
     if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
     if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+    // (measurements only: an irregular cadence for the call-by-call forms below)
+    auto delta_of = [&](int tick) { return c->run_delta_period > 0 && ((tick / c->run_delta_period) & 1) ? delta * 1.25 : delta; };
     if (c->run_as_reference) {  // measurement: the reference's own schedule, call by call
         for (int f = 0; f < frames; ++f) {
-            if (ow_status st = ow_update(c, delta, params, count); st != OW_OK) return st;
+            if (ow_status st = ow_update(c, delta_of(f), params, count); st != OW_OK) return st;
             for (int k = 0; k < count; ++k)
                 if (ow_status st = ow_process(c); st != OW_OK) return st;
         }
@@ -1186,7 +1210,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         f = frames;
     }
     for (; f < frames; ++f) {
-        ow_status st = ow_update_all(c, delta, params, count);
+        ow_status st = ow_update_all(c, c->run_as_calls ? delta_of(f) : delta, params, count);
         if (st != OW_OK) return st;
     }
     return OW_OK;

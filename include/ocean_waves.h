@@ -174,8 +174,9 @@ ow_status ow_process(ow_context *ctx);
  * (this tick's times + delta) together with its own pass 2; the next call checks the speculation against what it is actually given (count,
  * every FP32 time and tile length bit for bit, no spectrum to regenerate, nothing else has run in between) and, on a hit, costs one merged
  * launch instead of two.  Ticks of up to 1 Mi texels (the layer-parallel compact family) compute pass 1 of as many of the next ticks as the
- * delta has repeated, up to FOUR, in one launch, and the calls in between launch pass 2 alone (1024^2 x 1: 29.9 -> 20.3 us per tick).  A miss
- * discards the speculated work (never more than the repeats have saved); results are bit-identical either way.  Single-batch ticks of the compact families only (map_size >= 256; up to 4 Mi
+ * caller's cadence predicts, up to FOUR, in one launch, and the calls in between launch pass 2 alone (1024^2 x 1: 29.9 -> 20.3 us per tick).  The
+ * prediction: inside a run of equal deltas no further than the caller's previous run went, beyond it as far as this run has outlasted it (a
+ * caller whose delta changes every k updates is never speculated across a change).  A miss discards the speculated work; results are bit-identical either way.  Single-batch ticks of the compact families only (map_size >= 256; up to 4 Mi
  * texels per tick); off under OW_FLAG_NO_TICK_GROUPS.  ow_lookahead_stats: calls served from work computed ahead, launches that carried some. */
 ow_status ow_update_all(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
 ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *speculated);
