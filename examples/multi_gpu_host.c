@@ -98,6 +98,17 @@ int main(int argc, char **argv) {
         CHECK(ow_group_get_maps(g, c, d, m));
         sum = fnv1a(m, bytes, fnv1a(d, bytes, sum));
     }
+    {   /* the model the measurement is to be read against: cascades share nothing, so without the exchange the group's rate is the
+         * sum of its devices' rates; a shard's two maps (16 B/texel) cross ONE xGMI link to the consumer (~153 GB/s per link, point to point:
+         * the root's seven inbound links carry one sender each), and the gather hides under the ticks in between while
+         * gather_every >= 1.25 x (link time / tick time). */
+        const double tick_ms = plain / ticks * 1e3, link_ms = 16.0 * n * n * per / 153e9 * 1e3;
+        int k_model = (int)(1.25 * link_ms / tick_ms) + 1;
+        printf("model: per-device tick %.4f ms (measured, no gather); one shard's gather = %zu bytes = %.4f ms at 153 GB/s per link; the gather hides "
+               "under compute from gather_every >= %d; expected maps_per_s with gather = maps_per_s_no_gather while gather_every (%d) >= that, else "
+               "bounded by the links at %.1f maps/s\n",
+               tick_ms, (size_t)16 * n * n * per, link_ms, k_model, gather_every, (double)total * gather_every / (link_ms * 1e-3));
+    }
     printf("devices=%d cascades=%d map_size=%d ticks=%d maps_per_s_no_gather=%.1f maps_per_s_gather_every_%d=%.1f gather_copy_ms=%.4f "
            "bytes_per_shard=%zu link_GBps_per_shard=%.2f checksum=%016llx time=%.17g\n",
            cfg.num_devices, total, n, ticks, (double)total * ticks / plain, gather_every, (double)total * ticks / gathered, (double)copy_ms,

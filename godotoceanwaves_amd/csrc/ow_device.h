@@ -134,8 +134,22 @@ OW_DEV cplx csubi(cplx a, cplx b) { return __builtin_elementwise_fma(b.yx, cplx{
 OW_DEV cplx cscale(cplx a, float s) { return a * s; }
 // a * (c + i s) with compile-time c, s
 OW_DEV cplx cmul_const(cplx a, float c, float sn) { return __builtin_elementwise_fma(a.yx, cplx{-sn, sn}, a * cplx{c, c}); }
-// a * b, general
-OW_DEV cplx cmul(cplx a, cplx b) { return __builtin_elementwise_fma(a.yy * cplx{-1.0f, 1.0f}, b.yx, a.xx * b); }
+// a * b, general: (a.x b.x, a.x b.y) + a.y * (-b.y, b.x).  The sign of the one half rides on the packed instruction's neg_lo modifier, which the
+// compiler does not use for a per-half sign (it emits a third instruction, a.yy * (-1, 1)); spelled out, a complex multiply is TWO packed
+// instructions -- thirty fewer per 1024-point transform (round 5).  Same products, same fma: bit-identical.
+#ifndef OW_CMUL_NEG_LO
+#define OW_CMUL_NEG_LO 1
+#endif
+OW_DEV cplx cmul(cplx a, cplx b) {
+#if OW_CMUL_NEG_LO
+    const cplx t = a.xx * b;
+    cplx r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+#else
+    return __builtin_elementwise_fma(a.yy * cplx{-1.0f, 1.0f}, b.yx, a.xx * b);
+#endif
+}
 #else
 OW_DEV cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
 OW_DEV cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
@@ -458,6 +472,36 @@ OW_DEV void sincos_phase(float ph, float &sn, float &cs) {
     sn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) ^ flip);
     cs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c) ^ flip);
 }
+// The same, returned as m = (cos, sin) = exp(i ph) for the packed complex arithmetic.  On the device the two polynomials -- independent Horner
+// chains in the same z -- run as ONE chain of packed instructions (v_pk_fma_f32: each half is the IEEE fma of the scalar form, so the
+// results are bit-identical to sincos_phase; round 5: eleven scalar fma / mul per texel become five packed ones).
+#ifndef OW_SINCOS_PACKED
+#define OW_SINCOS_PACKED 1
+#endif
+OW_DEV cplx expi_phase(float ph) {
+#if OW_DEVICE_BUILD && OW_SINCOS_PACKED
+    const float n = __builtin_rintf(ph * 0.318309886183790672f);
+    float r = __builtin_fmaf(-n, 3.140625f, ph);
+    r = __builtin_fmaf(-n, 9.67502593994140625e-4f, r);
+    r = __builtin_fmaf(-n, 1.509957990978376432e-7f, r);
+    const float z = r * r;
+    const cplx zz = cplx{z, z};
+    cplx p = cplx{-2.654252000411361e-07f, 2.6343420813645935e-06f};  // (cos chain, sin chain)
+    p = __builtin_elementwise_fma(p, zz, cplx{2.478597525623627e-05f, -0.00019822614558506757f});
+    p = __builtin_elementwise_fma(p, zz, cplx{-0.0013888811226934195f, 0.008333241567015648f});
+    p = __builtin_elementwise_fma(p, zz, cplx{0.0416666679084301f, -0.1666666567325592f});
+    p = p * zz;
+    // cos = (q z) z + (1 - z / 2),  sin = (p z) r + r
+    const cplx m = __builtin_elementwise_fma(p, cplx{z, r}, cplx{__builtin_fmaf(-0.5f, z, 1.0f), r});
+    const uint32_t flip = (uint32_t)(int)n << 31;  // (-1)^n as a sign bit
+    const float mx = m.x, my = m.y;
+    return cplx{__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mx) ^ flip), __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, my) ^ flip)};
+#else
+    float sn, cs;
+    sincos_phase(ph, sn, cs);
+    return cplx{cs, sn};
+#endif
+}
 
 // returns x, but the compiler cannot see that: stops it from keeping (instead of recomputing) cheap
 // per-texel terms across long code regions
@@ -541,6 +585,14 @@ OW_DEV uint16_t f2h(float f) {
     return (uint16_t)(sign | q);
 #endif
 }
+// two floats -> two IEEE halves in one word (lo | hi << 16), each rounded to nearest even exactly like f2h.  gfx950 has the packed conversion
+// (v_cvt_pk_f16_f32: same rounding mode, same denormal handling as v_cvt_f16_f32 -- checked over all 2^32 inputs of either slot,
+// tools/cvtcheck.hip): one instruction where two conversions, a mask and a shift-or were four (round 5).  Spelled as the instruction for
+// f2h's reason: a C cast would fuse a producing multiply into the conversion.
+#ifndef OW_CVT_PK
+#define OW_CVT_PK 1
+#endif
+OW_DEV uint32_t f2h2(float lo, float hi);
 OW_DEV float h2f(uint16_t h) {
 #if OW_DEVICE_BUILD
     return (float)__builtin_bit_cast(_Float16, h);
@@ -558,6 +610,15 @@ OW_DEV float h2f(uint16_t h) {
     float f;
     __builtin_memcpy(&f, &x, 4);
     return f;
+#endif
+}
+OW_DEV uint32_t f2h2(float lo, float hi) {
+#if OW_DEVICE_BUILD && OW_CVT_PK
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#else
+    return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
 #endif
 }
 
@@ -652,6 +713,31 @@ struct TickGroupArgs {
     int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
 };
+// One launch of the TICK-PAIR kernels (k_tick_pair_c, k_tick_pair_c_split) -- pass 2 of one batch, pass 1 of the next -- needs one row of
+// times, two scratch bases and the two block counts: 256 bytes with the cascades' constants instead of FrameArgs + TickGroupArgs' 950
+// (round 5: the kernarg segment of the headline kernel 1 052 -> 376 bytes; same-lease A/B in profiles/r05_ab_rounds.txt).
+#ifndef OW_PAIR_SLIM_ARGS
+#define OW_PAIR_SLIM_ARGS 1
+#endif
+struct PairFrame {  // CascadeFrame without the time (pass 1 takes it from PairArgs::time1, pass 2 has no use for it) and the fault word
+    float tile_x, tile_y, whitecap, foam_grow_rate, foam_decay;
+    int32_t cascade;
+};
+struct PairArgs {
+    PairFrame c[8];      // per launch slot
+    float time1[8];      // FP32-narrowed params.time of the pass-1 batch, per launch slot
+    int32_t tbase2, tbase1;  // first scratch slot of the pass-2 / pass-1 batch
+    int32_t n2, n1;          // blocks of each pass (multiples of 8; either may be 0)
+    int32_t first2, first1;  // first launch slot of each batch
+    int32_t fault, pad;      // fault-injection bits of this launch (tests)
+};
+OW_HD CascadeFrame pair_frame(const PairArgs &g, int launch_slot) {
+    const PairFrame &f = g.c[launch_slot];
+    CascadeFrame cf;
+    cf.tile_x = f.tile_x, cf.tile_y = f.tile_y, cf.time = g.time1[launch_slot], cf.whitecap = f.whitecap;
+    cf.foam_grow_rate = f.foam_grow_rate, cf.foam_decay = f.foam_decay, cf.cascade = f.cascade, cf.fault = g.fault;
+    return cf;
+}
 // fault-injection bits (tests): kFaultRowSync = the second wave of every pair never publishes its epoch
 constexpr int32_t kFaultRowSync = 1;
 constexpr int kMaxCascades = 8;
@@ -700,6 +786,10 @@ OW_DEV void gstore8h(GBuf b, uint32_t voff, uint32_t soff, u16x4 v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), b.r, (int)voff, (int)soff, AUX);
 }
 template <int AUX = 0>
+OW_DEV void gstore8w(GBuf b, uint32_t voff, uint32_t soff, uint32_t w0, uint32_t w1) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, b.r, (int)voff, (int)soff, AUX);
+}
+template <int AUX = 0>
 OW_DEV void gstore16(GBuf b, uint32_t voff, uint32_t soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), b.r, (int)voff, (int)soff, AUX);
 }
@@ -720,6 +810,11 @@ template <int AUX = 0>
 OW_DEV void gstore8(GBuf b, uint32_t voff, uint32_t soff, cplx v) { __builtin_memcpy(b.p + voff + soff, &v, 8); }
 template <int AUX = 0>
 OW_DEV void gstore8h(GBuf b, uint32_t voff, uint32_t soff, u16x4 v) { __builtin_memcpy(b.p + voff + soff, &v, 8); }
+template <int AUX = 0>
+OW_DEV void gstore8w(GBuf b, uint32_t voff, uint32_t soff, uint32_t w0, uint32_t w1) {
+    const uint32_t w[2] = {w0, w1};
+    __builtin_memcpy(b.p + voff + soff, w, 8);
+}
 template <int AUX = 0>
 OW_DEV void gstore16(GBuf b, uint32_t voff, uint32_t soff, f32x4 v) { __builtin_memcpy(b.p + voff + soff, &v, 16); }
 #endif
@@ -798,16 +893,14 @@ struct Pass1 {
     static OW_DEV void modulate(cplx *h, const cplx *a, const cplx *b, const float *om, float time) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            float sn, cs;
-            sincos_phase(mul_rn(om[j], time), sn, cs);
+            const cplx m = expi_phase(mul_rn(om[j], time));  // (cos, sin)
             // reference: h = h0 * m + conj(h0(-k)) * conj(m) with the texel (a, conj(b)), m = (cs, sn).  Expanded:
             //   h.re = (a.re + b.re) cs - (a.im + b.im) sn ,  h.im = (a.re - b.re) sn + (a.im - b.im) cs
             const cplx pp = cadd(a[j], b[j]), qq = csub(a[j], b[j]);
 #if OW_DEVICE_BUILD
-            const cplx m = cplx{cs, sn};
             const cplx t1 = pp * m, t2 = qq * m.yx;
 #else
-            const cplx t1 = cplx{pp.x * cs, pp.y * sn}, t2 = cplx{qq.x * sn, qq.y * cs};
+            const cplx t1 = cplx{pp.x * m.x, pp.y * m.y}, t2 = cplx{qq.x * m.y, qq.y * m.x};
 #endif
             h[j] = cplx{t1.x - t1.y, t2.x + t2.y};
             opaque_inplace(h[j]);
@@ -1138,24 +1231,26 @@ struct Pass2 {
     template <bool F32>
     static OW_DEV void after_f2(const cplx *f2, uint32_t *hz_pk, float *c2, uint32_t tex, GBuf f32_c) {
 #pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int sl = OutMap<N>::slot_of(o);
-            const float hz = f2[sl].x, dhz_dx = f2[sl].y;
-            c2[o] = dhz_dx * dhz_dx;
-            const uint32_t hh = f2h(hz);
-            // packed HERE (pure ops would otherwise sink to the store, leaving both halves live across two transforms)
-            hz_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(hz_pk[o / 2] | (hh << 16))) : hh;
-            if (F32) f32_put(f32_c, tex, o, 2, hz);
+        for (int o = 0; o < P; o += 2) {
+            const int sl = OutMap<N>::slot_of(o), sl1 = OutMap<N>::slot_of(o + 1);
+            c2[o] = f2[sl].y * f2[sl].y;
+            c2[o + 1] = f2[sl1].y * f2[sl1].y;
+            // packed HERE (pure ops would otherwise sink to the store, leaving both floats live across two transforms)
+            hz_pk[o / 2] = (uint32_t)opaque((int)f2h2(f2[sl].x, f2[sl1].x));
+            if (F32) {
+                f32_put(f32_c, tex, o, 2, f2[sl].x);
+                f32_put(f32_c, tex, o + 1, 2, f2[sl1].x);
+            }
         }
     }
     template <bool F32, int AUX>
     static OW_DEV void after_f0(const cplx *f0, const uint32_t *hz_pk, int t, int xp, uint32_t tex, GBuf disp_c, GBuf f32_c) {
-        const uint16_t w = (uint16_t)(((xp ^ t) & 1) << 15);  // see after_layer0
+        const uint32_t w = (uint32_t)((xp ^ t) & 1) << 31;  // see after_layer0: the sign of .w's zero, as the upper half of the texel's second word
 #pragma unroll
         for (int o = 0; o < P; ++o) {
             const int sl = OutMap<N>::slot_of(o);
-            const uint16_t hz_h = (uint16_t)((hz_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
-            gstore8h<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(f0[sl].x), f2h(f0[sl].y), hz_h, w});
+            const uint32_t hz_h = (hz_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu;
+            gstore8w<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, f2h2(f0[sl].x, f0[sl].y), hz_h | w);
             if (F32) {
                 f32_put(f32_c, tex, o, 0, f0[sl].x);
                 f32_put(f32_c, tex, o, 1, f0[sl].y);
@@ -1165,15 +1260,17 @@ struct Pass2 {
     template <bool F32>
     static OW_DEV void after_f1(const cplx *f1, float *dhx_dx, uint32_t *gx_pk, uint32_t tex, GBuf f32_c) {
 #pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int sl = OutMap<N>::slot_of(o);
+        for (int o = 0; o < P; o += 2) {
+            const int sl = OutMap<N>::slot_of(o), sl1 = OutMap<N>::slot_of(o + 1);
             dhx_dx[o] = f1[sl].x;
-            const float gx = f1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o]));
-            const uint32_t gh = f2h(gx);
-            gx_pk[o / 2] = (o & 1) ? (uint32_t)opaque((int)(gx_pk[o / 2] | (gh << 16))) : gh;
+            dhx_dx[o + 1] = f1[sl1].x;
+            const float gx = f1[sl].y * fast_rcp(1.0f + fabsf(dhx_dx[o])), gx1 = f1[sl1].y * fast_rcp(1.0f + fabsf(dhx_dx[o + 1]));
+            gx_pk[o / 2] = (uint32_t)opaque((int)f2h2(gx, gx1));
             if (F32) {
                 f32_put(f32_c, tex, o, 3, gx);
                 f32_put(f32_c, tex, o, 5, dhx_dx[o]);
+                f32_put(f32_c, tex, o + 1, 3, gx1);
+                f32_put(f32_c, tex, o + 1, 5, dhx_dx[o + 1]);
             }
         }
     }
@@ -1182,25 +1279,30 @@ struct Pass2 {
     static OW_DEV void after_f3(const cplx *f3, const float *dhx_dx, const float *c2, const uint32_t *gx_pk, uint32_t *foam_pk,
                                 uint32_t tex, const CascadeFrame &cf, GBuf norm_c, GBuf f32_c) {
 #pragma unroll
-        for (int o = 0; o < P; ++o) {
-            const int sl = OutMap<N>::slot_of(o);
-            const float dhy_dz = f3[sl].x, dhz_dz = f3[sl].y;
-            const float jac = (1.0f + dhx_dx[o]) * (1.0f + dhz_dz) - c2[o];
-            const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
-            float foam = h2f((uint16_t)((foam_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu));
-            foam = mul_rn(foam, cf.foam_decay);
-            foam = foam + mul_rn(foam_factor, cf.foam_grow_rate);
-            foam = fminf(fmaxf(foam, 0.0f), 1.0f);
-            const uint32_t foam_h = f2h(foam);
-            foam_pk[o / 2] = (o & 1) ? ((foam_pk[o / 2] & 0xFFFFu) | (foam_h << 16)) : ((foam_pk[o / 2] & 0xFFFF0000u) | foam_h);
-            const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
-            const uint16_t gx_h = (uint16_t)((gx_pk[o / 2] >> (16 * (o & 1))) & 0xFFFFu);
-            gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{gx_h, f2h(gy), f2h(dhx_dx[o]), (uint16_t)foam_h});
-            if (F32) {
-                f32_put(f32_c, tex, o, 4, gy);
-                f32_put(f32_c, tex, o, 6, foam);
-                f32_put(f32_c, tex, o, 7, jac);
+        for (int o = 0; o < P; o += 2) {  // two texels at a time: one word of foam_pk / gx_pk
+            float foam[2], gy[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int sl = OutMap<N>::slot_of(o + e);
+                const float dhy_dz = f3[sl].x, dhz_dz = f3[sl].y;
+                const float jac = (1.0f + dhx_dx[o + e]) * (1.0f + dhz_dz) - c2[o + e];
+                const float foam_factor = -fminf(0.0f, jac - cf.whitecap);
+                float fm = h2f((uint16_t)((foam_pk[o / 2] >> (16 * e)) & 0xFFFFu));
+                fm = mul_rn(fm, cf.foam_decay);
+                fm = fm + mul_rn(foam_factor, cf.foam_grow_rate);
+                foam[e] = fminf(fmaxf(fm, 0.0f), 1.0f);
+                gy[e] = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
+                if (F32) {
+                    f32_put(f32_c, tex, o + e, 4, gy[e]);
+                    f32_put(f32_c, tex, o + e, 6, foam[e]);
+                    f32_put(f32_c, tex, o + e, 7, jac);
+                }
             }
+            foam_pk[o / 2] = f2h2(foam[0], foam[1]);
+            const uint32_t gy_pk = f2h2(gy[0], gy[1]), gxw = gx_pk[o / 2];
+            // normal texel = (gx, gy | dhx_dx, foam) as two words
+            gstore8w<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, (gxw & 0xFFFFu) | (gy_pk << 16), f2h2(dhx_dx[o], foam[0]));
+            gstore8w<AUX>(norm_c, tex * 8u, (uint32_t)(T * (o + 1)) * 8u, (gxw >> 16) | (gy_pk & 0xFFFF0000u), f2h2(dhx_dx[o + 1], foam[1]));
         }
     }
 
@@ -1218,10 +1320,11 @@ struct Pass2 {
         foam = fminf(fmaxf(foam, 0.0f), 1.0f);
         const float gy = dhy_dz * fast_rcp(1.0f + fabsf(dhz_dz));
         const float gx = l1.y * fast_rcp(1.0f + fabsf(dhx_dx));
-        const uint16_t foam_h = f2h(foam);
-        const uint16_t w = (uint16_t)(((xp ^ t) & 1) << 15);
-        gstore8h<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(gx), f2h(gy), f2h(dhx_dx), foam_h});
-        gstore8h<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, u16x4{f2h(l0.x), f2h(l0.y), f2h(l1.x), w});
+        const uint32_t n1 = f2h2(dhx_dx, foam);
+        const uint16_t foam_h = (uint16_t)(n1 >> 16);
+        const uint32_t w = (uint32_t)((xp ^ t) & 1) << 31;
+        gstore8w<AUX>(norm_c, tex * 8u, (uint32_t)(T * o) * 8u, f2h2(gx, gy), n1);
+        gstore8w<AUX>(disp_c, tex * 8u, (uint32_t)(T * o) * 8u, f2h2(l0.x, l0.y), (uint32_t)f2h(l1.x) | w);
         if (F32) {
             f32_put(f32_c, tex, o, 0, l0.x);
             f32_put(f32_c, tex, o, 1, l0.y);

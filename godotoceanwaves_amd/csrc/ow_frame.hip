@@ -106,17 +106,26 @@ template <int N, bool F32>
 static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
     if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
         return hipErrorInvalidValue;
-    if constexpr (plan_split(N)) {  // 8-wave blocks of both kinds: 4 columns (pass 2), 4 rows (pass 1)
-        g.n2 = g.slots2 * (N / PairSplitGeo<N>::kCols);
-        g.n1 = g.slots1 * (N / 4);
-        if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-        launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, args, g, (Stamp *)nullptr);
-        return hipGetLastError();
-    }
-    g.n2 = g.slots2 * (N / kWgRows);
-    g.n1 = g.slots1 * (N / kWgRows);
+    constexpr int per2 = plan_split(N) ? N / PairSplitGeo<N>::kCols : N / kWgRows;  // blocks per cascade: 4 columns / 4 rows at 2048 (8-wave blocks of
+    constexpr int per1 = plan_split(N) ? N / 4 : N / kWgRows;                       // both kinds), 8 columns / 8 rows below
+    g.n2 = g.slots2 * per2;
+    g.n1 = g.slots1 * per1;
     if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-    if constexpr (!plan_split(N)) launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+#if OW_PAIR_SLIM_ARGS
+    PairArgs pa;
+    for (int i = 0; i < kMaxCascades; ++i) {
+        const CascadeFrame &cf = args.c[i];
+        pa.c[i] = PairFrame{cf.tile_x, cf.tile_y, cf.whitecap, cf.foam_grow_rate, cf.foam_decay, cf.cascade};
+        pa.time1[i] = g.time1[0][i];
+    }
+    pa.tbase2 = g.tbase2[0], pa.tbase1 = g.tbase1[0], pa.n2 = g.n2, pa.n1 = g.n1, pa.first2 = g.first2, pa.first1 = g.first1;
+    pa.fault = args.c[0].fault, pa.pad = 0;
+    if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, pa, (Stamp *)nullptr);
+    else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, pa);
+#else
+    if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, args, g, (Stamp *)nullptr);
+    else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
+#endif
     return hipGetLastError();
 }
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----

@@ -194,20 +194,29 @@ int tick_group_depth_for(const ow_context *c, int count) {
 }
 void plan_tick_groups(ow_context *c, uint32_t flags) {
     c->group_max_count = c->group_depth = c->pair_slots = 0;
-    // measurement knobs, read HERE and nowhere else (ow_create): the order of the stream of tick pairs (1 = tick-major), and their batch size in
-    // Mi texels -- the scratch is sized from pair_slots, which follows from it, and a value that changed between ow_create and ow_run would let
-    // the merged launches write past that scratch
     c->pair_tick_block = 0;
     c->group_depth_forced = 0;
     c->run_delta_period = 0;
+    c->ahead_depth = ow_context::Lookahead::kMaxAhead;
+    c->pair_texels = kPairTexels;
+    // the two forms of the tick groups' work items can be pinned per context (tests hold every form to the same bits at every size)
+    c->group_p1_form = (flags & OW_FLAG_GROUP_P1_COMPACT) ? 1 : (flags & OW_FLAG_GROUP_P1_LP) ? 0 : -1;
+    c->group_p2_form = (flags & OW_FLAG_GROUP_P2_PIPE) ? 1 : (flags & OW_FLAG_GROUP_P2_PLAIN) ? 0 : -1;
+#ifdef OW_MEASUREMENT_KNOBS
+    // Measurement knobs of A/B builds (scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS): the SHIPPED library reads nothing from the
+    // environment.  Read HERE and nowhere else (ow_create): the scratch is sized from pair_slots, which follows from the batch size, and a value
+    // that changed between ow_create and ow_run would let the merged launches write past that scratch.
+    //   OW_DEBUG_RUN_DELTA_CHANGE_EVERY  the call-by-call forms of ow_run switch between delta and 1.25 delta every that many ticks (changes RESULTS)
+    //   OW_DEBUG_TICK_GROUP_DEPTH        ticks per launch of the tick groups        OW_DEBUG_LOOKAHEAD_DEPTH  ticks of pass 1 computed ahead at most
+    //   OW_DEBUG_PAIR_TICK_BLOCK         ticks a batch runs through before the stream of tick pairs moves on (1 = tick-major)
+    //   OW_DEBUG_PAIR_TEXELS             batch size of the tick pairs in Mi texels
     if (const char *e = getenv("OW_DEBUG_RUN_DELTA_CHANGE_EVERY")) c->run_delta_period = std::max(0, std::min(1 << 20, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_DEPTH")) c->group_depth_forced = std::max(0, std::min((int)ow::kMaxTickGroup, atoi(e)));
-    c->ahead_depth = ow_context::Lookahead::kMaxAhead;
     if (const char *e = getenv("OW_DEBUG_LOOKAHEAD_DEPTH")) c->ahead_depth = std::max(1, std::min((int)ow_context::Lookahead::kMaxAhead, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));
-    c->pair_texels = kPairTexels;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
+#endif
     if ((flags & OW_FLAG_NO_TICK_GROUPS) || !ow::tick_pairs_supported(c->n)) return;
     for (int count = 1; count <= c->cascades; ++count) {
         int sizes[OW_MAX_CASCADES];
@@ -219,14 +228,12 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     if (best == 0) return;
     c->group_max_count = best;
     c->group_depth = tick_group_depth_for(c, best);
-    // measurement knob (scripts/group_p1_body.py): force one pass-1 item form in the tick groups; -1 = the runtime's own choice
-    c->group_p1_form = -1;
-    if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P1")) c->group_p1_form = strcmp(e, "compact") == 0 ? 1 : strcmp(e, "lp") == 0 ? 0 : -1;
-    c->group_p2_form = -1;
-    if (const char *e = getenv("OW_DEBUG_TICK_GROUP_P2")) c->group_p2_form = strcmp(e, "pipe") == 0 ? 1 : strcmp(e, "plain") == 0 ? 0 : -1;
 }
-// The scratch intermediate of ONE batch is all that ow_update / ow_process / ow_update_all ever need, and all that ow_create
-// allocates; the merged launches of ow_run keep 2 * depth ticks (groups) or two batches (pairs) in flight and grow it on first use.
+// One batch of scratch intermediate is what a tick launched one pass at a time needs.  The look-ahead of ow_update_all / ow_process keeps
+// more in flight -- the pair kernel two batches, the group kernel a ring of five groups -- and ow_create allocates THAT (lookahead_scratch_slots):
+// the per-frame calls never allocate, so memory use is what ow_create left behind and no frame pays a hipMalloc + synchronize (round 4 grew the
+// scratch inside the first speculating call).  Only ow_run -- the throughput form, whose merged launches keep 2 * depth ticks (groups: up to
+// kGroupScratchBytes) in flight -- still grows it on first use.
 int base_scratch_slots(const ow_context *c) { return std::min(c->layers, max_batch(c)); }
 ow_status ensure_scratch(ow_context *c, int slots) {
     if (slots <= c->scratch_slots) return OW_OK;
@@ -315,6 +322,11 @@ ow_status consume_status(ow_context *c) {
     *c->status_host = 0u;                          // the word is consumed; later batches start clean ...
     c->maps_faulted |= c->enqueued_since_sync;     // ... but what the faulted batches left behind stays marked until those layers are recomputed
     c->enqueued_since_sync = 0;
+    // ... and so does whatever those launches computed AHEAD: a speculated pass 1 (of cascades that are not even enqueued yet, or of the same
+    // cascade one tick later at 2048^2, where pass 1 has a bounded wait of its own) may be as corrupt as the maps.  The queue is dropped: the
+    // ticks after a fault recompute their pass 1.
+    c->la.armed = false;
+    c->la.queued = 0;
     for (int i = 0; i < OW_MAX_CASCADES; ++i)
         if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
     return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
@@ -510,6 +522,17 @@ int lookahead_mode(const ow_context *c, int count) {
     if (fam == 3 && c->pair_slots > 0 && pair_batches(c, count, sizes) == 1) return 1;
     if (fam == 4 && ow::tick_groups_supported(c->n) && count <= c->group_max_count) return 2;
     return 0;
+}
+// launch slots of scratch the look-ahead can ever ask for in this context (lookahead_launch: groups * stride), over every cascade count a
+// call may come with -- ow_update_all with 1 .. cascades, ow_process with one
+int lookahead_scratch_slots(const ow_context *c) {
+    int slots = 0;
+    for (int count = 1; count <= c->cascades; ++count) {
+        const int mode = lookahead_mode(c, count);
+        if (mode == 1) slots = std::max(slots, 2 * c->pair_slots);
+        if (mode == 2) slots = std::max(slots, (ow_context::Lookahead::kMaxAhead + 1) * count);
+    }
+    return slots;
 }
 // What a caller wants launched: pass 2 of `now_count` cascades (launch-slot order) and, ahead of time, pass 1 of the cascades its next
 // `ahead_ticks` launches will take at the FP32 times they WILL be processed with -- KNOWN where the cascades are armed (ow_process: the next
@@ -803,7 +826,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->run_as_calls = (cfg->flags & OW_FLAG_RUN_AS_CALLS) != 0;
     c->run_as_reference = (cfg->flags & OW_FLAG_RUN_AS_REFERENCE_SCHEDULE) != 0;
     plan_tick_groups(c, cfg->flags);
-    if (ensure_scratch(c, base_scratch_slots(c)) != OW_OK) return bail(OW_ERR_NOMEM);
+    if (ensure_scratch(c, std::max(base_scratch_slots(c), lookahead_scratch_slots(c))) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -907,7 +930,10 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
         ow_status st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
-    if (delta == c->la.last_delta) {  // the caller's cadence (look-ahead: lookahead_tick / lookahead_process)
+    // the caller's cadence (look-ahead: lookahead_tick / lookahead_process).  "The same delta" tolerates a nanosecond: a fixed-step scene behind
+    // water.gd's rate limiter (:78, target + (time - next_update_time)) issues deltas that are equal up to the rounding noise of its FP64 clock,
+    // and what has to repeat for a hit is the FP32-narrowed TIME (ulp 7.6e-6 s from t = 64 s on), which the hit check compares bit for bit anyway
+    if (std::fabs(delta - c->la.last_delta) <= 1e-9) {
         if (c->la.streak < (1 << 30)) ++c->la.streak;
     } else {
         c->la.prev_run = c->la.streak + 1;
@@ -975,6 +1001,11 @@ ow_status ow_lookahead_stats(const ow_context *c, uint64_t *hits, uint64_t *spec
 
 ow_status ow_debug_inject_fault(ow_context *c, uint32_t fault_bits) {
     if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (fault_bits & 2u) {  // the status word as a faulting launch would leave it -- of the launches IN FLIGHT (look-ahead included), not of the next batch
+        if (c->status_host) __atomic_store_n(c->status_host, (uint32_t)ow::kStatusRowSyncTimeout, __ATOMIC_RELEASE);
+        fault_bits &= ~2u;
+        if (fault_bits == 0) return OW_OK;
+    }
     c->inject_fault = fault_bits;
     return OW_OK;
 }

@@ -108,17 +108,22 @@ typedef struct ow_config {
  *    through a block of up to 64 ticks before the stream moves on to the next batch, so that a launch pairs a batch with itself one tick
  *    later and re-reads its spectra and foam from the Infinity Cache: cascades are independent, the state ow_run leaves behind is the same.
  * Results are bit-identical to one launch per pass; this flag keeps ow_run on one pair of launches per tick (tests, measurements).
- * (Measurement knobs, read by ow_create: the environment variables OW_DEBUG_TICK_GROUP_P1 = "lp" | "compact" and OW_DEBUG_TICK_GROUP_P2 =
- * "plain" | "pipe" force one of the two forms of the groups' pass-1 / pass-2 work items, OW_DEBUG_TICK_GROUP_DEPTH = ticks per launch of the groups, OW_DEBUG_PAIR_TEXELS = batch size of the tick pairs
- * in Mi texels, OW_DEBUG_PAIR_TICK_BLOCK = ticks a batch runs through before the stream moves on (1 = tick-major), OW_DEBUG_LOOKAHEAD_DEPTH =
- * ticks of pass 1 one ow_update_all computes ahead at most (1 .. 4); unset, the runtime's own
- * choices.  Results do not depend on them.) */
+ * The shipped library reads NOTHING from the environment.  (A/B builds compiled with -DOW_MEASUREMENT_KNOBS read the OW_DEBUG_* variables listed
+ * in ow_runtime.hip plan_tick_groups once, in ow_create; one of them, OW_DEBUG_RUN_DELTA_CHANGE_EVERY, changes the deltas the call-by-call forms
+ * of ow_run issue and with them the results.) */
 #define OW_FLAG_NO_TICK_GROUPS 16u
 /* ow_run issues its ticks exactly as an external caller of ow_update_all would, one call per tick (no merging across the ticks of the run);
  * ow_update_all's own adaptive look-ahead stays on.  For measuring what tick-by-tick callers get without a host round trip per tick. */
 #define OW_FLAG_RUN_AS_CALLS 32u
 /* ... and as the reference's own schedule: per tick one ow_update and `count` ow_process calls (wave_generator.gd:56-63,90-109). */
 #define OW_FLAG_RUN_AS_REFERENCE_SCHEDULE 64u
+/* Tests / measurements: pin the form of the tick groups' work items, which the runtime otherwise picks by batch size -- pass 1 as
+ * layer-parallel items (one (8 rows, layer) per lane group) or as k_pass1c-shaped items (8 rows, all layers); pass 2 as plain blocks (a block
+ * walks through the ticks of its columns) or pipelined ones (the block's two halves on alternate ticks).  Results do not depend on them. */
+#define OW_FLAG_GROUP_P1_LP 0x100u
+#define OW_FLAG_GROUP_P1_COMPACT 0x200u
+#define OW_FLAG_GROUP_P2_PLAIN 0x400u
+#define OW_FLAG_GROUP_P2_PIPE 0x800u
 
 typedef struct ow_context ow_context;
 
@@ -176,8 +181,13 @@ ow_status ow_process(ow_context *ctx);
  * launch instead of two.  Ticks of up to 1 Mi texels (the layer-parallel compact family) compute pass 1 of as many of the next ticks as the
  * caller's cadence predicts, up to FOUR, in one launch, and the calls in between launch pass 2 alone (1024^2 x 1: 29.9 -> 20.3 us per tick).  The
  * prediction: inside a run of equal deltas no further than the caller's previous run went, beyond it as far as this run has outlasted it (a
- * caller whose delta changes every k updates is never speculated across a change).  A miss discards the speculated work; results are bit-identical either way.  Single-batch ticks of the compact families only (map_size >= 256; up to 4 Mi
- * texels per tick); off under OW_FLAG_NO_TICK_GROUPS.  ow_lookahead_stats: calls served from work computed ahead, launches that carried some. */
+ * caller whose delta changes every k updates is never speculated across a change).  "The same delta" tolerates one nanosecond: a fixed-step scene
+ * behind water.gd's rate limiter issues deltas that are equal up to the rounding noise of its FP64 clock, and what a hit needs is the FP32-narrowed
+ * time, which is compared bit for bit anyway.  A miss discards the speculated work; results are bit-identical either way.  Single-batch ticks of
+ * the compact families only (map_size >= 256; up to 4 Mi texels per tick); off under OW_FLAG_NO_TICK_GROUPS.  The scratch the look-ahead keeps in
+ * flight (the pair kernel two batches, the group kernel a ring of five groups: at most a few hundred MiB) is allocated by ow_create: the per-frame
+ * calls never allocate.  A device-side failure reported by a synchronising call also drops whatever had been computed ahead.
+ * ow_lookahead_stats: calls served from work computed ahead, launches that carried some. */
 ow_status ow_update_all(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
 ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *speculated);
 
@@ -425,9 +435,11 @@ int32_t ow_last_batch_cascades(const ow_context *ctx);
  * never inside a simulation.  cascades_per_launch = how many cascades one launch of that batch covered. */
 ow_status ow_probe_kernel_times(ow_context *ctx, int32_t reps, float *pass1_ms, float *pass2_ms, int32_t *cascades_per_launch);
 
-/* Test hook: fault bits applied to the NEXT batch only.  bit 0: the second wave of every wave pair of the 2048^2 kernels
- * never publishes its rendezvous epoch, so its partner's bounded wait gives up -- exercises the status-word path above.
- * Never set in normal operation. */
+/* Test hook.  bit 0, applied to the NEXT batch only: the second wave of every wave pair of the 2048^2 kernels never publishes its rendezvous
+ * epoch, so its partner's bounded wait gives up -- exercises the status-word path above (a pending bit 0 keeps the look-ahead off).
+ * bit 1, immediate: the device status word is set as a faulting launch would leave it, i.e. the failure is that of the launches IN FLIGHT
+ * -- speculated pass-1 work included: the next synchronising call reports it, marks the layers enqueued since the last synchronisation and
+ * drops whatever had been computed ahead.  Never set in normal operation. */
 ow_status ow_debug_inject_fault(ow_context *ctx, uint32_t fault_bits);
 
 /* Thread-local description of the last error returned on this thread ("" if none). */

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """ow_run in tick groups: ticks per launch (OW_DEBUG_TICK_GROUP_DEPTH, read by ow_create) against the runtime's own rule.
     python scripts/group_depth.py [n:c:d,d,.. ...]   us per tick, median of 7 x 400 ticks, one process per cell"""
+# NOTE (round 5): the OW_DEBUG_* variables are read only by a library built with -DOW_MEASUREMENT_KNOBS:
+#   scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS ;  OCEAN_WAVES_LIB=godotoceanwaves_amd/csrc/build/variants/knobs.so python scripts/<this>.py
+# (the work-item forms of the tick groups are ow_config flags now: WaveGenerator.group_forms)
 import os
 import subprocess
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tick groups: layer-parallel pass-1 items against k_pass1c-shaped ones (OW_DEBUG_TICK_GROUP_P1=lp|compact).  us per tick of ow_run, and whether the
+"""tick groups: layer-parallel pass-1 items against k_pass1c-shaped ones (WaveGenerator.group_forms = OW_FLAG_GROUP_P1_LP | _COMPACT).  us per tick of ow_run, and whether the
 maps after the run are bit-identical between the two"""
 import os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,8 @@ cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(256, 1)
 for n, c in cases:
     row, sums = [], []
     for body in ("0", "1", "off"):
-        os.environ["OW_DEBUG_TICK_GROUP_P1"] = {"0": "lp", "1": "compact", "off": ""}[body]
         best = 1e9
-        gen = WaveGenerator(); gen.map_size = n; gen.tick_groups = body != 'off'; gen.init_gpu(max(2, c))
+        gen = WaveGenerator(); gen.map_size = n; gen.tick_groups = body != 'off'; gen.group_forms = ({"0": "lp", "1": "compact", "off": None}[body], None); gen.init_gpu(max(2, c))
         params = [WaveCascadeParameters(**cascade_preset(i)) for i in range(c)]
         gen.run(UPDATE_DELTA, params, 37); gen.sync()
         h = hashlib.sha1()

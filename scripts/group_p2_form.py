@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tick groups: plain pass-2 blocks against the pipelined form (OW_DEBUG_TICK_GROUP_P2=plain|pipe).  us per tick of ow_run, and whether
+"""tick groups: plain pass-2 blocks against the pipelined form (WaveGenerator.group_forms = OW_FLAG_GROUP_P2_PLAIN | _PIPE).  us per tick of ow_run, and whether
 the maps after 37 ticks are bit-identical"""
 import os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,8 @@ cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(256, 1)
 for n, c in cases:
     row, sums = [], []
     for form in ("plain", "pipe"):
-        os.environ["OW_DEBUG_TICK_GROUP_P2"] = form
         best = 1e9
-        gen = WaveGenerator(); gen.map_size = n; gen.init_gpu(max(2, c))
+        gen = WaveGenerator(); gen.map_size = n; gen.group_forms = (None, form); gen.init_gpu(max(2, c))
         params = [WaveCascadeParameters(**cascade_preset(i)) for i in range(c)]
         gen.run(UPDATE_DELTA, params, 37); gen.sync()
         h = hashlib.sha1()

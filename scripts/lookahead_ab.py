@@ -2,6 +2,9 @@
 """ow_update_all tick by tick (OW_FLAG_RUN_AS_CALLS) with its adaptive look-ahead against one launch per pass (OW_FLAG_NO_TICK_GROUPS), and -- for
 the layer-parallel compact family, whose look-ahead launch is the group kernel with one tick per side -- how many ticks of pass 1 a launch computes ahead
 (OW_DEBUG_LOOKAHEAD_DEPTH) and the two forms of its pass-1 items (OW_DEBUG_TICK_GROUP_P1), both read by ow_create.  One process per variant.   python scripts/lookahead_ab.py [n:c ...]   us per tick, median of 7 x 400"""
+# NOTE (round 5): the OW_DEBUG_* variables are read only by a library built with -DOW_MEASUREMENT_KNOBS:
+#   scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS ;  OCEAN_WAVES_LIB=godotoceanwaves_amd/csrc/build/variants/knobs.so python scripts/<this>.py
+# (the work-item forms of the tick groups are ow_config flags now: WaveGenerator.group_forms)
 import os
 import statistics
 import subprocess
@@ -21,6 +24,7 @@ def child(n, c, mode):
     gen.run_as_reference = mode in ("reference", "reference_nomerge")
     if mode == "reference_nomerge":
         gen.tick_groups = False
+    gen.group_forms = (os.environ.get("OW_DEBUG_TICK_GROUP_P1") or None, None)  # (the script's own convention: the library does not read it)
     gen.init_gpu(max(2, c))
     params = [WaveCascadeParameters(**cascade_preset(i)) for i in range(c)]
     gen.run(UPDATE_DELTA, params, 2000)

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """ow_update_all tick by tick (OW_FLAG_RUN_AS_CALLS) on the layer-parallel compact family: ticks of pass 1 per look-ahead launch
 (OW_DEBUG_LOOKAHEAD_DEPTH) x form of the pass-1 items (OW_DEBUG_TICK_GROUP_P1).   python scripts/lookahead_depth.py [n:c ...]   us per tick"""
+# NOTE (round 5): the OW_DEBUG_* variables are read only by a library built with -DOW_MEASUREMENT_KNOBS:
+#   scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS ;  OCEAN_WAVES_LIB=godotoceanwaves_amd/csrc/build/variants/knobs.so python scripts/<this>.py
+# (the work-item forms of the tick groups are ow_config flags now: WaveGenerator.group_forms)
 import os
 import subprocess
 import sys

@@ -3,6 +3,9 @@
 (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE) with the delta switching between two values every k ticks (OW_DEBUG_RUN_DELTA_CHANGE_EVERY, read by
 ow_create), against the same calls with one launch per pass (OW_FLAG_NO_TICK_GROUPS), whose cost does not depend on the cadence.
     python scripts/lookahead_misses.py [n:c ...]   us per tick, median of 7 x 400 ticks, one process per cell"""
+# NOTE (round 5): the OW_DEBUG_* variables are read only by a library built with -DOW_MEASUREMENT_KNOBS:
+#   scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS ;  OCEAN_WAVES_LIB=godotoceanwaves_amd/csrc/build/variants/knobs.so python scripts/<this>.py
+# (the work-item forms of the tick groups are ow_config flags now: WaveGenerator.group_forms)
 import os
 import subprocess
 import sys

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """2048^2: ow_run's tick pairs (k_tick_pair_c_split) tick-major against cascade-major in blocks of 8 / 64 ticks, and one launch per pass.
 One process per variant (the knobs are read by ow_create).   python scripts/pairs_2048.py [n:c ...]   us per tick, median (min) of 7 x 200 ticks"""
+# NOTE (round 5): the OW_DEBUG_* variables are read only by a library built with -DOW_MEASUREMENT_KNOBS:
+#   scripts/build_variant.sh knobs -DOW_MEASUREMENT_KNOBS ;  OCEAN_WAVES_LIB=godotoceanwaves_amd/csrc/build/variants/knobs.so python scripts/<this>.py
+# (the work-item forms of the tick groups are ow_config flags now: WaveGenerator.group_forms)
 import os
 import statistics
 import subprocess

@@ -57,6 +57,30 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
         assert 0.9 < rf["traffic"] / rf["bytes_per_launch"] < 1.15 and rf["traffic_detail"]["full_launch_equivalents"] == 80
     else:
         assert rf["traffic"] is None or "NOT measured by this run" in rf["traffic_source"]
+    # round 5: the four ways of driving the boundary are timed interleaved, with the clocks in the record; the scene's own cadence and -- on the
+    # headline run -- BASELINE configs C5 / C2 ride in the same line, early in `roofline` (the driver's record keeps its first keys)
+    il = d["interleaving"]
+    assert il["regions_per_block"] >= 1 and il["blocks_of_value"] >= 3 and len(il["block_medians_ms_per_step"]) >= 3
+    assert d["clock_priming"]["probes"] >= 1 and d["clock_priming"]["last_probe_ms_per_step"] > 0
+    assert "clocks" in rf and set(rf["clocks"]) >= {"source", "idle_before", "run"}
+    if rf["clocks"]["source"]:   # (amdsmi present: the figures are there and plausible)
+        assert rf["clocks"]["run"]["sclk_mhz"] is None or 300 <= rf["clocks"]["run"]["sclk_mhz"] <= 3500
+    sc = rf["scene_schedule"]
+    for key in ("144hz_jitter5pct", "60hz_jitter5pct", "144hz_fixed_clock"):
+        e = sc[key]
+        assert e["us_per_update"] > 0 and e["maps_per_s"] > 0 and 0.0 <= e["lookahead_hit_rate"] <= 1.0
+        assert 0 < e["frame_gpu_us_p50"] <= e["frame_gpu_us_p99"] <= e["frame_gpu_us_max"] and 0.0 < e["frac"] < 0.85
+    assert sc["144hz_fixed_clock"]["us_per_update"] <= 1.1 * sc["144hz_jitter5pct"]["us_per_update"]   # (a regular cadence never costs more)
+    keys = list(rf)
+    assert keys.index("scene_schedule") < 12 and keys.index("clocks") < 12 and keys.index("traffic") < 8
+    if not flags:
+        oc = {e["workload"]: e for e in rf["other_configs"]}
+        assert set(oc) == {"2048^2 x 4", "256^2 x 4"} and keys.index("other_configs") < 10
+        assert oc["2048^2 x 4"]["kernel"] == "k_tick_pair_c_split" and oc["256^2 x 4"]["kernel"] == "k_tick_group_c_lp"
+        for e in oc.values():
+            assert e["value"] > 0 and 0.0 < e["frac"] < 0.85 and e["repeats"] >= 3 and e["ms_per_step"] > 0
+    else:
+        assert "other_configs" not in rf
     # round 4: the CPU leg runs first, the GPU work is one contiguous stretch and says how long it was
     assert d["timed_region_s"] == d["timed_seconds"] > 0 and d["gpu_phase_s"] > d["timed_region_s"]
     assert d["timed_ticks_per_region"] == 40 and d["regions_per_sync"] == 1 and d["scaling"] == "weak"

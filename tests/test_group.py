@@ -287,3 +287,43 @@ def test_a_faulted_shard_keeps_its_gathered_layers_refused_until_a_clean_gather(
     grp.get_maps(1)
     grp.sample_surface([[3.0, 4.0]], scales)
     grp.free()
+
+
+def test_c4_exact_shape_eight_shards_overlapped_gathers_against_the_oracle():
+    """BASELINE config C4's exact shape on the one device of the box: 1024^2, EIGHT shards of one cascade each, every shard through the whole
+    remote path (OW_GROUP_FLAG_FORCE_PEER_PATH: snapshot in stream order, side stream, hipMemcpyPeerAsync into the consumer's layer slot),
+    210 ticks through ow_group_run with a gather begun every 16 ticks and left to overlap the next chunk -- then all eight gathered layers are
+    held to the ORACLE after the same 210 ticks (FP16 maps within one ulp + 1e-5 of the channel maximum, the recurrent foam within one
+    step), and to the live maps of their shards bit for bit.  (the group tests used at most four shards.)"""
+    n, shards, ticks, every = 1024, 8, 210, 16
+    grp = WaveGeneratorGroup()
+    grp.map_size = n
+    grp.force_peer_path = True
+    grp.init_gpu([0] * shards, 1, root=0)
+    assert grp.num_cascades == 8
+    params = [WaveCascadeParameters(**cascade_preset(ci)) for ci in range(shards)]
+    done = 0
+    while done < ticks:
+        k = min(every, ticks - done)
+        grp.run(UPDATE_DELTA, params, k)
+        grp.gather_begin()            # overlaps the next chunk's ticks; a new gather waits for the previous one's snapshot buffer only
+        done += k
+    grp.gather_wait()
+    grp.sync()
+    ms, nbytes = grp.gather_stats()
+    assert nbytes == n * n * 16 and ms > 0.0
+    og = H.oracle_generator(n, list(range(shards)), native=True)
+    for _ in range(ticks):
+        og.update_all(UPDATE_DELTA)
+    for c in range(shards):
+        got_d, got_n = grp.get_maps(c)
+        live_d, live_n = grp.shard(c).get_maps(0)
+        assert np.array_equal(bits(got_d), bits(live_d)) and np.array_equal(bits(got_n), bits(live_n)), c   # the last gather followed the last tick
+        assert H.fp16_close(got_d, og.displacement(c)) <= 1.0, c
+        assert H.fp16_close(got_n[..., :3], og.normal(c)[..., :3]) <= 1.0, c
+        foam_err = np.abs(got_n[..., 3].astype(np.float64) - og.normal(c)[..., 3].view(np.float16).astype(np.float64))
+        # (recurrent FP16 state over 210 ticks, as in tests/test_golden.py's 1000-frame loop: within two steps everywhere, within one on all but a vanishing share)
+        assert foam_err.max() <= 2 * H.TOL_FOAM_ABS and (foam_err > H.TOL_FOAM_ABS).mean() < 1e-3, (c, foam_err.max())
+    assert params[7].time == pytest.approx(120.0 + np.pi * 7 + ticks * UPDATE_DELTA)
+    og.close()
+    grp.free()

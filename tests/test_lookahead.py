@@ -242,7 +242,7 @@ def test_run_as_reference_schedule_is_update_plus_one_process_per_cascade():
     assert hits == 3 + 28 * 4 and a.pass_num_cascades_remaining == 0
 
 
-@pytest.mark.parametrize("n,count", [(256, 4), (512, 2), (1024, 1), (512, 8), (2048, 1)])
+@pytest.mark.parametrize("n,count", [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8), (2048, 1)])  # = fuzz_schedule.CONFIGS
 def test_random_schedules_hold_the_bits_of_a_context_that_never_merges(n, count):
     """scripts/fuzz_schedule.py: random sequences of update_all (repeating and changing deltas), update + some or all of its process calls, short
     runs, live edits, fewer cascades, restored foam -- every merged launch shape against OW_FLAG_NO_TICK_GROUPS, bit for bit"""
@@ -251,8 +251,40 @@ def test_random_schedules_hold_the_bits_of_a_context_that_never_merges(n, count)
     spec = importlib.util.spec_from_file_location("fuzz_schedule", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_schedule.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
+    assert (n, count) in fz.CONFIGS
     served = 0
-    for seed in (11, 12, 13):
-        calls, hits = fz.schedule(n, count, seed, ops=30)
+    for seed in (11, 12, 13, 14, 15):   # 8 configurations x 5 fixed seeds = 40 schedules in the suite; the 320-schedule run stays a script
+        calls, hits = fz.schedule(n, count, seed, ops=30 if n >= 2048 else 40)
         served += hits
     assert served > 0   # (the schedules do reach the look-ahead)
+
+
+@pytest.mark.parametrize("n,ids", [(1024, [0, 1, 2, 3]), (256, [0, 1, 2, 3]), (2048, [1])])
+def test_a_fault_reported_while_work_is_queued_ahead_drops_the_queue(n, ids):
+    """ADVICE r4 (ow_runtime.hip consume_status): a launch that faults may have written speculated pass-1 entries, too -- of cascades not yet
+    enqueued, or of the same cascade one tick later.  Once the status word has been consumed nothing would refuse them any more, so the
+    synchronising call that reports the fault also drops the queue: the ticks after it recompute their pass 1 (no hit on poisoned work) and
+    land on the bits of a context that never speculates.  The fault is injected as the status word a faulting launch IN FLIGHT would leave
+    (ow_debug_inject_fault bit 1); bit 0, a fault of the next batch, keeps the look-ahead off and cannot reach a speculating launch."""
+    from godotoceanwaves_amd._lib import OceanWavesError, OW_ERR_HIP
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+    for _ in range(4):   # armed: every call from the third on hits and computes ahead again
+        a.update_all(UPDATE_DELTA, pa); b.update_all(UPDATE_DELTA, pb)
+    hits0, spec0 = a.lookahead_stats()
+    assert hits0 == 2 and spec0 >= 1
+    a.debug_inject_fault(2)
+    with pytest.raises(OceanWavesError) as e:
+        a.sync()
+    assert e.value.status == OW_ERR_HIP
+    for i in range(len(ids)):   # the layers enqueued since the last synchronisation stay refused until recomputed
+        with pytest.raises(OceanWavesError):
+            a.get_maps(i)
+    a.update_all(UPDATE_DELTA, pa); b.update_all(UPDATE_DELTA, pb)
+    hits1, _ = a.lookahead_stats()
+    assert hits1 == hits0, "the tick after a reported fault must not consume work computed ahead by the faulted launches"
+    same(a, b, len(ids))   # (the injected word corrupted nothing: the recomputed tick is the never-merging context's, bit for bit)
+    for _ in range(3):     # ... and the look-ahead arms again
+        a.update_all(UPDATE_DELTA, pa); b.update_all(UPDATE_DELTA, pb)
+    same(a, b, len(ids))
+    assert a.lookahead_stats()[0] > hits1

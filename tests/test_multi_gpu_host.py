@@ -42,7 +42,9 @@ def test_c_program_and_python_group_agree(tmp_path, devices, per):
     n, ticks, every = 256, 40, 8
     r = subprocess.run([build(tmp_path), str(n), str(per), str(ticks), str(every), devices], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    out = dict(kv.split("=") for kv in r.stdout.split())
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("model: per-device tick") and "153 GB/s per link" in lines[0]   # the model the first real multi-GPU run is read against
+    out = dict(kv.split("=") for kv in lines[-1].split())
     shards = len(devices.split(","))
     assert int(out["devices"]) == shards and int(out["cascades"]) == shards * per and int(out["bytes_per_shard"]) == per * n * n * 16
     assert float(out["maps_per_s_no_gather"]) > 0 and float(out[f"maps_per_s_gather_every_{every}"]) > 0 and float(out["gather_copy_ms"]) > 0

@@ -2,7 +2,6 @@
 // (256^2 / 512^2 x 1..4 cascades: the layer-parallel kernels on the compact intermediate, k_pass1c_lp / k_pass2c_lp).
 //   * tick and per-kernel durations (hipEvents around back-to-back launches);
 //   * the launch floor: an empty kernel and a "one load, one store" kernel with the same grids;
-//   * the persistent tick-loop experiment (tools/tick_loop_experiment.h: measured and rejected);
 //   * per-wave phase stamps of both kernels (STAMPS instantiation), averaged over the waves that did work, plus the
 //     spread of wave start / end times over the launch (dispatch ramp, tail).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DKS_N=256 -I godotoceanwaves_amd/csrc tools/kbench_small.hip -o tools/kbench_small_256
@@ -14,7 +13,6 @@
 #include <vector>
 
 #include "ow_frame_kernels.h"
-#include "tick_loop_experiment.h"
 #include "ow_tables.h"
 
 #ifndef KS_N
@@ -147,33 +145,6 @@ int main(int argc, char **argv) {
     printf("one load -> one store per wave, pass-1 grid  : %7.2f us\n", time_it([&] { hipLaunchKernelGGL(k_touch, dim3(g1.x * g1.y), b1, 0, s, scratch, scratch + (1 << 17)); }, iters, s));
     printf("one load -> one store per wave, pass-2 grid  : %7.2f us\n", time_it([&] { hipLaunchKernelGGL(k_touch, g2, b2, 0, s, scratch, scratch + (1 << 17)); }, iters, s));
 
-    {   // the persistent tick loop: 16 ticks per cooperative launch
-        unsigned *counter;
-        CK(hipMalloc(&counter, 64));
-        CK(hipMemset(counter, 0, 64));
-        int per_cu = 0, dev = 0;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ticks_c_lp<N, false>, plan_lp_threads(N), 0));
-        hipDeviceProp_t prop;
-        CK(hipGetDeviceProperties(&prop, dev));
-        using TP = TickPlan<N>;
-        const int grid = std::min(std::max(TP::items_1(C), TP::items_2(C)), per_cu * prop.multiProcessorCount);
-        TickTimes times{};
-        for (int k = 0; k < kMaxTicksPerLaunch; ++k)
-            for (int i = 0; i < C; ++i) times.t[k][i] = 120.5f + i + 0.02f * k;
-        unsigned base = 0;
-        int slots = C, ticks = kMaxTicksPerLaunch;
-        auto loop = [&] {
-            void *params[] = {&buf, &args, &times, &slots, &ticks, &counter, &base};
-            CK(hipLaunchCooperativeKernel((const void *)k_ticks_c_lp<N, false>, dim3(grid), dim3(plan_lp_threads(N)), params, 0, s));
-            base += (unsigned)grid * ticks;
-        };
-        const float per_launch = time_it(loop, std::max(20, iters / 16), s);
-        printf("tick loop: %d blocks (%d per CU possible), %d phase-A items, %d phase-B items: %7.2f us per launch of %d ticks = %6.2f us per tick\n", grid, per_cu,
-               TP::items_1(C), TP::items_2(C), per_launch, ticks, per_launch / ticks);
-        unsigned st_word = 0;
-        CK(hipMemcpy(&st_word, buf.status, 4, hipMemcpyDeviceToHost));
-        printf("status word after the tick loops: 0x%x\n", st_word);
-    }
     {
         CK(hipMemset(st, 0, sizeof(Stamp) * nst));
         for (int i = 0; i < 50; ++i) { p1(); p2(); }
