@@ -890,7 +890,58 @@ struct Pass1 {
             }
         }
     }
+    // TWO TEXELS PER PACKED INSTRUCTION (round 5).  The chip runs these kernels at its power limit, so every vector instruction removed comes
+    // back as clock (profiles/r05_ab_rounds.txt), and a third of pass 1's instructions were per-texel SCALAR arithmetic on real coefficients --
+    // the phase reduction, the wave numbers, the layer coefficients.  Texels j and j + 1 of a lane now share one packed instruction for each of
+    // those steps (v_pk_mul / v_pk_fma: each half is the IEEE operation of the scalar form, so the results are bit-identical -- maps hashed against
+    // the one-texel build and round 4's library, profiles/r05_hash_maps.txt; the contraction choices of the scalar form, 1 + ky / |k| as ONE fma,
+    // are spelled out).  164 of k_pass1c<1024>'s 2 858 vector instructions go; measured, same box, alternating builds: 1024^2 x 4 51.66 -> 51.46 us
+    // per tick, 2048^2 x 4 229.2 -> 228.8, but 512^2 x 8 27.22 -> 27.51 (and at 256 the temporaries spill) -- so from N = 1024 on only.
+    // OW_P1_PAIRWISE=0 keeps the one-texel forms everywhere (A/B builds).
+    static constexpr bool kPairwise = N >= 1024;
+#ifndef OW_P1_PAIRWISE
+#define OW_P1_PAIRWISE 7  // bits: 1 = phase reduction (modulate), 2 = wave numbers, 4 = layer coefficients
+#endif
     static OW_DEV void modulate(cplx *h, const cplx *a, const cplx *b, const float *om, float time) {
+#if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 1)
+        if constexpr (kPairwise) {
+        // Texels j and j + 1 together, every value in "one texel per half" layout: nothing has to be shuffled between the steps.
+        //   reduction (sincos_phase's Cody-Waite, three steps)  ->  the two polynomials of sincos_phase, each for both texels  ->  sign (-1)^n
+        //   ->  h = (a + b) (c, s) combined as  h.re = fma(pp.re, c, -(pp.im s)),  h.im = fma(qq.im, c, qq.re s)  with pp = a + b, qq = a - b:
+        // exactly the operations (and the two fused products) the one-texel form compiles to -- bit-identical (scripts/hash_maps.py).
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const cplx ph = cplx{om[j], om[j + 1]} * cplx{time, time};  // the FP32-rounded products (spectrum_modulate.glsl:65): only a multiply and explicit fmas consume them
+            const cplx q = ph * cplx{0.318309886183790672f, 0.318309886183790672f};
+            const cplx n = cplx{__builtin_rintf(q.x), __builtin_rintf(q.y)};
+            cplx r = __builtin_elementwise_fma(-n, cplx{3.140625f, 3.140625f}, ph);
+            r = __builtin_elementwise_fma(-n, cplx{9.67502593994140625e-4f, 9.67502593994140625e-4f}, r);
+            r = __builtin_elementwise_fma(-n, cplx{1.509957990978376432e-7f, 1.509957990978376432e-7f}, r);
+            const cplx z = r * r;
+            cplx ps = cplx{2.6343420813645935e-06f, 2.6343420813645935e-06f};
+            ps = __builtin_elementwise_fma(ps, z, cplx{-0.00019822614558506757f, -0.00019822614558506757f});
+            ps = __builtin_elementwise_fma(ps, z, cplx{0.008333241567015648f, 0.008333241567015648f});
+            ps = __builtin_elementwise_fma(ps, z, cplx{-0.1666666567325592f, -0.1666666567325592f});
+            const cplx sn = __builtin_elementwise_fma(ps * z, r, r);
+            cplx pc = cplx{-2.654252000411361e-07f, -2.654252000411361e-07f};
+            pc = __builtin_elementwise_fma(pc, z, cplx{2.478597525623627e-05f, 2.478597525623627e-05f});
+            pc = __builtin_elementwise_fma(pc, z, cplx{-0.0013888811226934195f, -0.0013888811226934195f});
+            pc = __builtin_elementwise_fma(pc, z, cplx{0.0416666679084301f, 0.0416666679084301f});
+            const cplx cs = __builtin_elementwise_fma(pc * z, z, __builtin_elementwise_fma(cplx{-0.5f, -0.5f}, z, cplx{1.0f, 1.0f}));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t flip = (uint32_t)(int)(e ? n.y : n.x) << 31;  // (-1)^n as a sign bit
+                const float se = e ? sn.y : sn.x, ce = e ? cs.y : cs.x;
+                const float s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, se) ^ flip), c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, ce) ^ flip);
+                const cplx pp = cadd(a[j + e], b[j + e]), qq = csub(a[j + e], b[j + e]);
+                h[j + e] = cplx{__builtin_fmaf(pp.x, c, -mul_rn(pp.y, s)), __builtin_fmaf(qq.y, c, mul_rn(qq.x, s))};
+                opaque_inplace(h[j + e]);
+            }
+            if (j % 4 == 2) OW_SCHED_FENCE();
+        }
+        return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const cplx m = expi_phase(mul_rn(om[j], time));  // (cos, sin)
@@ -922,6 +973,20 @@ struct Pass1 {
     static OW_DEV float kx_of(int j, float kx0, float dkx) { return __builtin_fmaf((float)(T * rot(j)), dkx, kx0); }
     static OW_DEV void wave_numbers(float *ik, int t, float ky, float dkx) {
         const float kx0 = (float)(t - N / 2) * dkx, ky2 = __builtin_fmaf(ky, ky, 1e-30f);
+#if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 2)
+        if constexpr (kPairwise) {
+#pragma unroll
+            for (int j = 0; j < P; j += 2) {
+                const cplx kx = kx_pair(j, kx0, dkx);
+                const cplx k2 = __builtin_elementwise_fma(kx, kx, cplx{ky2, ky2});
+                const cplx rk = cplx{fast_rsq(k2.x), fast_rsq(k2.y)};
+                const cplx ikp = __builtin_elementwise_fma(cplx{-1e-6f, -1e-6f} * rk, rk, rk);
+                ik[j] = ikp.x;
+                ik[j + 1] = ikp.y;
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const float kx = kx_of(j, kx0, dkx);
@@ -929,6 +994,12 @@ struct Pass1 {
             ik[j] = __builtin_fmaf(-1e-6f * rk, rk, rk);
         }
     }
+#if OW_DEVICE_BUILD
+    // kx of texels j and j + 1 (kx_of twice, one packed fma)
+    static OW_DEV cplx kx_pair(int j, float kx0, float dkx) {
+        return __builtin_elementwise_fma(cplx{(float)(T * rot(j)), (float)(T * rot(j + 1))}, cplx{dkx, dkx}, cplx{kx0, kx0});
+    }
+#endif
 
     // d[j] = packed layer L at texel x (spectrum_modulate.glsl:72-89); each layer is h times a complex
     // coefficient of the wave vector (u = k / |k|):  L0 = i(1+uy) h, L1 = (-ky + i ux) h, L2 = i(kx - ky uy) h,
@@ -979,13 +1050,39 @@ struct Pass1 {
     template <int L, class Hook = NoHook>
     static OW_DEV void layer_input_c(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx, Hook after_group = Hook()) {
         const float kx0 = (float)(t - N / 2) * dkx;
+#if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 4)
+        cplx cf2 = cplx{0.0f, 0.0f};
+        constexpr bool kPairCoef = kPairwise;
+#endif
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const cplx ih = cmuli(h[j]);
+#if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 4)
+            // the real coefficient of i h for texels j, j + 1 in one go (even j computes, odd j takes the upper half); kx, ux as scalars only
+            // where the Nyquist column needs them (slot kColSlot, an even slot)
+            static_assert(kColSlot % 2 == 0, "the pair (kColSlot, kColSlot + 1) is computed at kColSlot");
+            cplx kx2 = cplx{0.0f, 0.0f}, ux2 = kx2;
+            if (!kPairCoef) {
+                const float kx1 = kx_of(j, kx0, dkx), ux1 = kx1 * ik[j];
+                kx2 = cplx{kx1, 0.0f}, ux2 = cplx{ux1, 0.0f};
+                const float c1 = (L == 0) ? __builtin_fmaf(ky, ik[j], 1.0f) : (L == 1) ? ux1 : __builtin_fmaf(-kx1, ux1, kx1);
+                cf2 = cplx{c1, c1};
+            } else if (j % 2 == 0) {
+                kx2 = kx_pair(j, kx0, dkx);
+                const cplx ikp = cplx{ik[j], ik[j + 1]};
+                ux2 = kx2 * ikp;
+                cf2 = ux2;                                                                                       // L == 1
+                if (L == 0) cf2 = __builtin_elementwise_fma(cplx{ky, ky}, ikp, cplx{1.0f, 1.0f});              // 1 + ky / |k| (one fma, as the scalar form contracts)
+                if (L == 2) cf2 = __builtin_elementwise_fma(-kx2, ux2, kx2);
+            }
+            const float kx = kx2.x, ux = ux2.x;  // (read at j == kColSlot only)
+            d[j] = cscale(ih, (j % 2 == 0) ? cf2.x : cf2.y);
+#else
             const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
             if (L == 0) d[j] = cscale(ih, 1.0f + ky * ik[j]);
             if (L == 1) d[j] = cscale(ih, ux);
             if (L == 2) d[j] = cscale(ih, __builtin_fmaf(-kx, ux, kx));
+#endif
             if (j == kColSlot && L > 0) {
                 const cplx line = (L == 1) ? cplx{0.0f, 0.0f} : cadd(cscale(h[j], ux * ky), cscale(ih, -(ux * kx)));
                 d[j] = cplx{t == 0 ? line.x : d[j].x, t == 0 ? line.y : d[j].y};

@@ -91,6 +91,7 @@ struct ow_context {
         int prev_run = 1;              // updates in the caller's previous run of equal deltas (1: none that says anything)
         uint64_t hits = 0, speculated = 0;
         bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
+        int certain = 0;               // ticks the caller GUARANTEES will follow with the same delta (ow_run's own remaining ticks): speculated without evidence
     } la;
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
@@ -681,7 +682,7 @@ bool lookahead_tick(ow_context *c, double delta, int count, ow_status *out) {
     LookaheadPlan pl;
     std::memset(&pl, 0, sizeof(pl));
     pl.now_count = count;
-    const int repeats = std::isfinite(delta) ? predicted_repeats(c->la) : 0;
+    const int repeats = std::isfinite(delta) ? std::max(predicted_repeats(c->la), c->la.certain) : 0;
     const bool speculate = repeats >= 1;
     pl.next_count = speculate ? count : 0;
     // as many ticks ahead as the caller's cadence predicts (up to four)
@@ -724,6 +725,64 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
     pl.next_count = k > 0 ? 1 : 0;
     pl.ahead_ticks = k;
     return lookahead_launch(c, pl, out);
+}
+
+// ow_update on the reference's schedule -- ow_process calls will follow, one cascade each, highest index first: pass 1 of the cascades those calls
+// will take is launched NOW, all in ONE launch (the group kernel's pass-1 items, one cascade per "tick": up to four cascades = up to 4 Mi texels,
+// a launch that fills the chip), and every ow_process then launches its pass 2 alone.  Nothing is guessed: the records are the armed ones, and each
+// ow_process checks what it finds (a live edit in between simply takes the ordinary two launches).  This is what a caller whose deltas never repeat
+// gets -- water.gd's rate limiter passes the elapsed time -- where the look-ahead ACROSS updates cannot arm: before (round 4) the first ow_process
+// of an update launched pass 1 of its own cascade alone (a quarter-filled launch), then pass 2 + the others' pass 1; and whatever an update left
+// for the next one to flush was recomputed from scratch although its pass 1 had long been done (the flush now consumes the queue, ow_update).
+// Round 5, the scene's cadence at 1024^2 x 4 (roofline.scene_schedule): 144 Hz frames 110 -> ?? us per update, 60 Hz 142 -> ??.
+void lookahead_prearm(ow_context *c) {
+    ow_context::Lookahead &la = c->la;
+    constexpr int kRing = ow_context::Lookahead::kMaxAhead;
+    if (la.armed && la.queued > 0) return;  // work computed ahead is waiting already (a regular cadence: the previous update's last ow_process guessed right or wrong -- its check comes with the call)
+    if (lookahead_mode(c, 1) != 2) return;  // the group kernel's form only (a cascade of the layer-parallel compact family: <= 1 Mi texels)
+    const int idx = c->pass_num_cascades_remaining - 1;
+    int depth = std::min(idx + 1, std::min(kRing, c->ahead_depth));
+    for (int k = 0; k < depth; ++k) {
+        const ow_cascade_params &p = c->pass_parameters[idx - k];
+        if (p.should_generate_spectrum || validate_record(p, idx - k) != OW_OK) depth = k;
+    }
+    if (depth < 1) return;
+    const int groups = kRing + 1, stride = 1;
+    if (ensure_scratch(c, groups * stride) != OW_OK) return;
+    const int cur = la.cur_group % groups;
+    ow::FrameArgs args;
+    ow::TickGroupArgs ga;
+    std::memset(&args, 0, sizeof(args));
+    std::memset(&ga, 0, sizeof(ga));
+    la.head = 0;
+    for (int k = 0; k < depth; ++k) {
+        const ow_cascade_params &p = c->pass_parameters[idx - k];
+        la.group[k] = (cur + 1 + k) % groups;
+        ga.tbase1[k] = la.group[k] * stride;
+        args.c[k] = frame_of(p, idx - k);            // pass-1 "tick" k = launch slot k (first1 = 0, step1 = 1): tile lengths and layer from it, the time from time1
+        la.time[k][0] = ga.time1[k][0] = (float)p.time;
+        la.cascade[k][0] = idx - k;
+        la.tile_x[k][0] = p.tile_length[0];
+        la.tile_y[k][0] = p.tile_length[1];
+    }
+    ga.d2 = 0;
+    ga.d1 = depth;
+    ga.first1 = 0;
+    ga.step1 = 1;
+    ga.slots = 1;
+    ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
+    if (ow::launch_tick_group(c->n, args, ga, c->buf, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        la.armed = false;
+        la.queued = 0;
+        return;  // (nothing is lost: the ow_process calls take the ordinary path -- and report the device's state themselves)
+    }
+    la.queued = depth;
+    la.armed = true;
+    la.count = 1;
+    la.mode = 2;
+    la.cur_group = cur;
+    la.speculated += 1;
 }
 
 ow_status check_cascade(const ow_context *c, int cascade) {
@@ -911,7 +970,12 @@ void ow_destroy(ow_context *c) {
     if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }
 
-ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
+namespace {
+ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, int32_t count, bool process_calls_follow);
+}
+ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int32_t count) { return update_impl(c, delta, params, count, true); }
+namespace {
+ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, int32_t count, bool process_calls_follow) {
     if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
     if (count < 1 || count > c->cascades)  // assert(parameters.size() != 0), :91
         return fail(OW_ERR_INVALID, "count %d outside [1,%d]", count, c->cascades);
@@ -927,7 +991,16 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
         // ow_update would run into it again.  (Armed records were validated on the way in, so only a HIP failure can end up here;
         // nothing of `params` has been touched yet, so the call can simply be repeated.)
         c->pass_num_cascades_remaining = 0;
-        ow_status st = enqueue(c, c->pass_parameters, idx, left);
+        ow_status st = OW_OK;
+        if (c->la.armed && c->la.queued > 0 && c->la.count == 1) {
+            // their pass 1 may be waiting in the queue (computed ahead for the ow_process calls that never came): one cascade at a time, in the
+            // order those calls would have taken them -- each is checked like any ow_process, a miss takes the ordinary two launches.  (Cascades
+            // are independent: the order of the flush does not show in any result.)
+            for (int i = left - 1; i >= 0 && st == OW_OK; --i)
+                if (!lookahead_process(c, i, &st)) st = enqueue(c, c->pass_parameters, &i, 1);
+        } else {
+            st = enqueue(c, c->pass_parameters, idx, left);
+        }
         if (st != OW_OK) return st;
     }
     // the caller's cadence (look-ahead: lookahead_tick / lookahead_process).  "The same delta" tolerates a nanosecond: a fixed-step scene behind
@@ -951,8 +1024,10 @@ ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int3
     }
     c->pass_count = count;
     c->pass_num_cascades_remaining = count;  // :109
+    if (process_calls_follow) lookahead_prearm(c);
     return OW_OK;
 }
+}  // namespace
 
 ow_status ow_set_cascade_params(ow_context *c, int32_t index, const ow_cascade_params *p) {
     if (!c || !p) return fail(OW_ERR_INVALID, "null argument");
@@ -982,7 +1057,7 @@ ow_status ow_process(ow_context *c) {  // :56-63
 }
 
 ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, int32_t count) {
-    ow_status st = ow_update(c, delta, params, count);
+    ow_status st = update_impl(c, delta, params, count, false);
     if (st != OW_OK) return st;
     int idx[OW_MAX_CASCADES];
     for (int i = 0; i < count; ++i) idx[i] = count - 1 - i;  // same order _process would take
@@ -1219,6 +1294,28 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         return OW_OK;
     }
     int f = 0;
+    // SINGLE-BATCH ticks of the compact family (1024^2 x 2 .. 4, 512^2 x 7 .. 8, 2048^2 x 1): the run is a tick-by-tick caller of ow_update_all whose
+    // next ticks are CERTAIN -- every tick launches its pass 2 together with pass 1 of the next one (k_tick_pair_c), the last tick of the run with
+    // a speculated pass 1 of the tick a NEXT run would start with (the cadence rule of ow_update_all: after a run of equal deltas, one more).
+    // Back-to-back runs are then one seamless stream of full pair launches: no ordinary first tick, no half-filled launches at the two ends of
+    // every run -- round 5 found the driver's 20-tick regions paying 2 us per tick for those (profiles/r05_run_overhead.txt).  Every tick is
+    // checked like any ow_update_all (records, dirty spectra, leftovers: the ordinary path takes what does not qualify); results bit-identical.
+    if (frames >= 3 && !c->run_as_calls && !c->no_merge && c->timing == 0 && std::isfinite(delta) && count >= 1 && count <= c->cascades &&
+        lookahead_mode(c, count) == 1) {
+        const uint64_t before = c->la.hits + c->la.speculated;
+        ow_status st = OW_OK;
+        for (; f < frames && st == OW_OK; ++f) {
+            c->la.certain = frames - f - 1;
+            st = ow_update_all(c, delta, params, count);
+        }
+        c->la.certain = 0;
+        if (st != OW_OK) return st;
+        if (c->la.hits + c->la.speculated != before) {  // (the pair kernel did launch: what ow_last_kernel_family / ow_tick_group_depth report for a run)
+            c->last_family = 6;
+            c->last_group_depth = 1;
+        }
+        return OW_OK;
+    }
     // the first tick always takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
     if (frames >= 1) {
         c->la.hold = frames >= 3 && !c->run_as_calls && !c->no_merge;  // (the run's own merged launches take over from tick 2 on)

@@ -170,7 +170,10 @@ ow_status ow_get_cascade_params(const ow_context *ctx, int32_t index, ow_cascade
  * The launch also carries pass 1 of the cascades the NEXT ow_process calls will take -- up to four of them (index - 1, index - 2, ..: their
  * armed records are known, nothing is guessed; behind an update's last cascade: the next update's cascades at time + delta, once the deltas
  * repeat), each checked when its call comes; the calls in between launch pass 2 alone.  A record edited in between (ow_set_cascade_params)
- * simply takes the ordinary two launches.  Bit-identical results.  (1024^2 x 4 on this schedule: 119 -> 85 us per update.) */
+ * simply takes the ordinary two launches.  Bit-identical results.  (1024^2 x 4 on this schedule: 119 -> 85 us per update.)
+ * Where nothing is waiting when an update arms its cascades -- the deltas of a scene behind water.gd's rate limiter never repeat -- ow_update
+ * itself launches pass 1 of the cascades the ow_process calls will take (up to four, ONE launch that fills the chip; map sizes up to 1024),
+ * and whatever an update leaves for the next one to flush (:94-98) is flushed from that queue instead of being recomputed. */
 ow_status ow_process(ow_context *ctx);
 
 /* Throughput mode: ow_update() followed by all armed cascades in ONE pair of kernel launches
