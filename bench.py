@@ -140,7 +140,7 @@ def cpu_baseline(n, cascades, seconds):
             "sample": f"{frames} ticks of {n}^2 x {cascades} cascades (oracle, OpenMP x{cores}, {dt:.1f} s)"}
 
 
-def measure_traffic(n, C, kernel, timeout_s=100):
+def measure_traffic(n, C, kernel, timeout_s=100, seamless=False):
     """Memory-side bytes per FULL launch of `kernel`, measured now: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit one: the TCC has
     four counter slots, MI355X_MICROARCH.md) over scripts/drive.py -- one ordinary tick, then 80 ticks through ow_run, i.e. the launches the timed
     region consists of -- with --kernel-trace beside the counters and nothing else.  FETCH_SIZE[KB] * 1024 * 2 (gfx950 tallies a 128-byte request
@@ -176,8 +176,9 @@ def measure_traffic(n, C, kernel, timeout_s=100):
             launches[ctr] = sum(c for _, c, _ in hit)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    # (ow_run's merged launches: a run's first and last launch carry one pass each = one full launch between them; other kernels: every launch is full)
-    full = max(1, launches["FETCH_SIZE"] - 1) if kernel.startswith("k_tick_") else max(1, launches["FETCH_SIZE"])
+    # (ow_run's merged launches: a run's first and last launch carry one pass each = one full launch between them -- except the seamless stream
+    #  of single-batch tick pairs, round 5, whose every launch carries both passes; other kernels: every launch is full)
+    full = max(1, launches["FETCH_SIZE"] - 1) if (kernel.startswith("k_tick_") and not seamless) else max(1, launches["FETCH_SIZE"])
     nbytes = (sums["FETCH_SIZE"] * 2.0 + sums["WRITE_SIZE"]) * 1024.0 / full
     return int(round(nbytes)), {"FETCH_SIZE_KB_sum": round(sums["FETCH_SIZE"], 1), "WRITE_SIZE_KB_sum": round(sums["WRITE_SIZE"], 1),
                                 "launches": launches["FETCH_SIZE"], "full_launch_equivalents": full}
@@ -957,10 +958,10 @@ def main():
                 # roofline.traffic measured by THIS run (after the timed work: the profiled child process shares the GPU with nothing)
                 rf = out["roofline"]
                 try:
-                    got, detail = measure_traffic(n, C, rf["kernel"])
+                    got, detail = measure_traffic(n, C, rf["kernel"], seamless=rf["kernel"].startswith("k_tick_pair_c") and rf["cascades_per_launch"] == C)
                     rf["traffic"] = got
                     rf["traffic_source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over scripts/drive.py, 80 ticks "
-                                            "through ow_run; FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch; between the XCD L2s and the "
+                                            "through ow_run; FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch (every pair launch of a single-batch run carries both passes); between the XCD L2s and the "
                                             "fabric, Infinity-Cache hits included")
                     rf["traffic_detail"] = detail
                     rf["traffic_bytes_per_texel"] = round(got / max(1, rf["bytes_per_launch"]) * rf["bytes_per_texel"], 2)

@@ -2,7 +2,7 @@
  * layers gathered to the consumer's device) the way a single-process host (C#, GDExtension) would drive it.
  *   gcc -O2 -std=c99 -Iinclude examples/multi_gpu_host.c -o multi_gpu_host -Lgodotoceanwaves_amd -locean_waves \
  *       -Wl,-rpath,$PWD/godotoceanwaves_amd -Wl,-rpath-link,/opt/rocm/lib -lm
- *   ./multi_gpu_host [map_size [cascades_per_device [ticks [gather_every [dev0,dev1,...]]]]]
+ *   ./multi_gpu_host [map_size [cascades_per_device [ticks [gather_every [dev0,dev1,... [peer]]]]]]      ("peer": every shard through the remote path, test hook)
  * Default device list: 0,0 (two shards on one device: exercises the whole path on a single-GPU box; OW_GROUP_FLAG_FORCE_PEER_PATH makes
  * both go through snapshot + side stream + hipMemcpyPeerAsync).  On a node: ./multi_gpu_host 1024 1 2000 16 0,1,2,3,4,5,6,7
  * Prints: maps/s without any gather, with a gather every `gather_every` ticks (overlapped), the copy time of one gather and the
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     {   /* device list */
         char list[256];
         snprintf(list, sizeof list, "%s", argc > 5 ? argv[5] : "0,0");
-        if (argc <= 5) cfg.flags |= OW_GROUP_FLAG_FORCE_PEER_PATH;
+        if (argc <= 5 || (argc > 6 && strcmp(argv[6], "peer") == 0)) cfg.flags |= OW_GROUP_FLAG_FORCE_PEER_PATH;
         for (char *tok = strtok(list, ","); tok && cfg.num_devices < OW_MAX_DEVICES; tok = strtok(NULL, ",")) cfg.device_ids[cfg.num_devices++] = atoi(tok);
     }
     cfg.root = 0;

@@ -715,10 +715,7 @@ struct TickGroupArgs {
 };
 // One launch of the TICK-PAIR kernels (k_tick_pair_c, k_tick_pair_c_split) -- pass 2 of one batch, pass 1 of the next -- needs one row of
 // times, two scratch bases and the two block counts: 256 bytes with the cascades' constants instead of FrameArgs + TickGroupArgs' 950
-// (round 5: the kernarg segment of the headline kernel 1 052 -> 376 bytes; same-lease A/B in profiles/r05_ab_rounds.txt).
-#ifndef OW_PAIR_SLIM_ARGS
-#define OW_PAIR_SLIM_ARGS 1
-#endif
+// (round 5: the kernarg segment of the headline kernel 1 052 -> 360 bytes; same-lease A/B in profiles/r05_ab_rounds.txt).
 struct PairFrame {  // CascadeFrame without the time (pass 1 takes it from PairArgs::time1, pass 2 has no use for it) and the fault word
     float tile_x, tile_y, whitecap, foam_grow_rate, foam_decay;
     int32_t cascade;

@@ -111,7 +111,6 @@ static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const De
     g.n2 = g.slots2 * per2;
     g.n1 = g.slots1 * per1;
     if (g.n2 + g.n1 < 1) return hipErrorInvalidValue;
-#if OW_PAIR_SLIM_ARGS
     PairArgs pa;
     for (int i = 0; i < kMaxCascades; ++i) {
         const CascadeFrame &cf = args.c[i];
@@ -122,10 +121,6 @@ static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const De
     pa.fault = args.c[0].fault, pa.pad = 0;
     if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, pa, (Stamp *)nullptr);
     else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, pa);
-#else
-    if constexpr (plan_split(N)) launch(k_tick_pair_c_split<N, F32>, dim3(g.n2 + g.n1), dim3(PairSplitGeo<N>::kThreads), s, lt, buf, args, g, (Stamp *)nullptr);
-    else launch(k_tick_pair_c<N, F32>, dim3(g.n2 + g.n1), dim3(plan_wg_threads(N)), s, lt, buf, args, g);
-#endif
     return hipGetLastError();
 }
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----

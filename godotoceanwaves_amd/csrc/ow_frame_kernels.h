@@ -1012,25 +1012,10 @@ struct PairSplitGeo {
     static constexpr int kLdsCplx = kP1Cplx > kP2Cplx ? kP1Cplx : kP2Cplx;
     static_assert(kCols * plan_T(N) == kThreads && 2 * kLdsCplx * (int)sizeof(cplx) <= 160 * 1024, "two blocks per CU, of either kind");
 };
-// kernel arguments of the two tick-pair kernels: PairArgs (376 bytes with the buffers), or -- A/B builds only, -DOW_PAIR_SLIM_ARGS=0 --
-// the tick groups' FrameArgs + TickGroupArgs (1 052 bytes) that rounds 3-4 shipped
-#if OW_PAIR_SLIM_ARGS
-#define OW_PAIR_PARAMS PairArgs g
-#define OW_PAIR_FRAME(ls) pair_frame(g, ls)
-#define OW_PAIR_TIME1(ls) g.time1[ls]
-#define OW_PAIR_TBASE2 g.tbase2
-#define OW_PAIR_TBASE1 g.tbase1
-#define OW_PAIR_FAULT g.fault
-#else
-#define OW_PAIR_PARAMS FrameArgs args, TickGroupArgs g
-#define OW_PAIR_FRAME(ls) args.c[ls]
-#define OW_PAIR_TIME1(ls) g.time1[0][ls]
-#define OW_PAIR_TBASE2 g.tbase2[0]
-#define OW_PAIR_TBASE1 g.tbase1[0]
-#define OW_PAIR_FAULT args.c[0].fault
-#endif
+// (the two tick-pair kernels take PairArgs: 360 bytes of kernarg with the buffers, where the tick groups' FrameArgs + TickGroupArgs are 1 052;
+//  same box, alternating builds: 52.08 -> 51.78 us per tick at 1024^2 x 4, profiles/r05_ab_rounds.txt)
 template <int N, bool F32, bool STAMPS = false>
-__global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_split(DeviceBuffers buf, OW_PAIR_PARAMS, Stamp *stamps = nullptr) {
+__global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_split(DeviceBuffers buf, PairArgs g, Stamp *stamps = nullptr) {
     static_assert(plan_split(N), "rows that span two waves (N = 2048)");
     using PG = PairSplitGeo<N>;
     using SG = typename PG::SG;
@@ -1057,16 +1042,16 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
         int *sync_flags = reinterpret_cast<int *>(lds + PG::kP2Tw + PG::kCols * plan_region_cplx(N));
         RowSync<N> rs;
         rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
-        rs.watch(buf.status, OW_PAIR_FAULT);
+        rs.watch(buf.status, g.fault);
         init_row_sync<N>(sync_flags, PG::kCols);
         constexpr int BPC = N / PG::kCols;
         const int slot = index / BPC, row0 = (index % BPC) * PG::kCols;
-        const CascadeFrame cf = OW_PAIR_FRAME(g.first2 + slot);
+        const CascadeFrame cf = pair_frame(g, g.first2 + slot);
         fetch_arguments(buf, cf);
         TablePrefetch<PG::kP2Tw, PG::kThreads> twp;
         twp.fetch(p2c_table<N>(buf));
         uint32_t foam_pk[kP / 2];
-        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, OW_PAIR_TBASE2 + slot, row0, tau, tw_lds, rows_lds, rs, [&] { twp.commit(tw_lds); }, foam_pk);
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2 + slot, row0, tau, tw_lds, rows_lds, rs, [&] { twp.commit(tw_lds); }, foam_pk);
         ws.write(stamps, PG::kThreads / 64, 100000ull);
         return;
     }
@@ -1074,9 +1059,9 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
     int slot, row0;
     p1_index_to_rows<N, kWgRows / 4>(index, slot, row0);
     const int launch_slot = g.first1 + slot;
-    const CascadeFrame cf = OW_PAIR_FRAME(launch_slot);
+    const CascadeFrame cf = pair_frame(g, launch_slot);
     fetch_arguments(buf, cf);
-    pass1c_split_item<N, 4, kAuxDefault, kAuxDefault>(buf, cf, OW_PAIR_TIME1(launch_slot), OW_PAIR_TBASE1 + slot, row0, OW_PAIR_FAULT, lds, lds + SG::TW,
+    pass1c_split_item<N, 4, kAuxDefault, kAuxDefault>(buf, cf, g.time1[launch_slot], g.tbase1 + slot, row0, g.fault, lds, lds + SG::TW,
                                                       reinterpret_cast<int *>(lds + SG::kLdsCplx), (int)threadIdx.x, [&](int k, float keep) { ws.at(k, keep); });
     ws.write(stamps, PG::kThreads / 64, 1000ull + (unsigned long long)row0);
 }
@@ -1561,7 +1546,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
 //  once the deeper scratch leaves the Infinity Cache (profiles/r02_tick_pairs_compact.txt).  N <= 1024: at 2048^2 the two passes'
 //  blocks are of another shape, k_tick_pair_c_split above.)
 template <int N, bool F32>
-__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, OW_PAIR_PARAMS) {
+__global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuffers buf, PairArgs g) {
     static_assert(!plan_row_spans_waves(N), "N <= 1024");
     __shared__ __attribute__((aligned(16))) cplx lds[plan_wg_lds_cplx(N)];
     cplx *tw_lds = lds;
@@ -1591,13 +1576,13 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
         p1_index_to_rows<N>(index, slot, row0);
     }
     const int launch_slot = (first ? g.first1 : g.first2) + slot;  // slot: index inside the batch = scratch slot of its intermediate
-    const CascadeFrame cf = OW_PAIR_FRAME(launch_slot);
+    const CascadeFrame cf = pair_frame(g, launch_slot);
     fetch_arguments(buf, cf);
     if (!first) {
         uint32_t foam_pk[kP / 2];
-        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, OW_PAIR_TBASE2 + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
+        pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2 + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs, [&] { tw_commit<N>(twp, tw_lds); }, foam_pk);
     } else {
-        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, OW_PAIR_TIME1(launch_slot), OW_PAIR_TBASE1 + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
+        pass1c_item<N, kAuxDefault, kAuxDefault>(buf, cf, g.time1[launch_slot], g.tbase1 + slot, row0, (int)threadIdx.x, tw_lds, rows_lds, rs,
                                                  [&] { tw_commit<N>(twp, tw_lds); }, [](int, float) {});
     }
 }

@@ -733,8 +733,9 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
 // ow_process checks what it finds (a live edit in between simply takes the ordinary two launches).  This is what a caller whose deltas never repeat
 // gets -- water.gd's rate limiter passes the elapsed time -- where the look-ahead ACROSS updates cannot arm: before (round 4) the first ow_process
 // of an update launched pass 1 of its own cascade alone (a quarter-filled launch), then pass 2 + the others' pass 1; and whatever an update left
-// for the next one to flush was recomputed from scratch although its pass 1 had long been done (the flush now consumes the queue, ow_update).
-// Round 5, the scene's cadence at 1024^2 x 4 (roofline.scene_schedule): 144 Hz frames 110 -> ?? us per update, 60 Hz 142 -> ??.
+// for the next one to flush was recomputed from scratch although its pass 1 had long been done (the flush now consumes the queue: flush_from_queue).
+// Round 5, the scene's cadence at 1024^2 x 4 (roofline.scene_schedule): 144 Hz frames 110 -> 83 us per update, 60 Hz 137-142 -> 81, the heaviest
+// frame 91 -> 61 us (144 Hz).
 void lookahead_prearm(ow_context *c) {
     ow_context::Lookahead &la = c->la;
     constexpr int kRing = ow_context::Lookahead::kMaxAhead;
@@ -749,7 +750,8 @@ void lookahead_prearm(ow_context *c) {
     if (depth < 1) return;
     const int groups = kRing + 1, stride = 1;
     if (ensure_scratch(c, groups * stride) != OW_OK) return;
-    const int cur = la.cur_group % groups;
+    const int cur = 0;  // (nothing is queued and everything launched so far precedes this launch in stream order: any group will do -- the entries then
+                        //  sit in groups 1 .. depth, consecutive scratch slots without a wrap of the ring, which is what flush_from_queue needs)
     ow::FrameArgs args;
     ow::TickGroupArgs ga;
     std::memset(&args, 0, sizeof(args));
@@ -783,6 +785,60 @@ void lookahead_prearm(ow_context *c) {
     la.mode = 2;
     la.cur_group = cur;
     la.speculated += 1;
+}
+
+// The flush of ow_update (wave_generator.gd:94-98: the cascades 0 .. left - 1 the previous arm never got to) from the queue: if pass 1 of EVERY
+// leftover is waiting there -- each entry checked exactly like a hit: cascade, FP32 time and tile lengths bit for bit, no spectrum to regenerate --
+// and the entries sit in consecutive scratch slots, the flush is ONE pass-2 launch over them, in the kernel family a batch of `left` cascades takes
+// anyway (launch_pass2 picks it from the batch size, as enqueue() would: the maps are bit-identical to the ordinary flush, whose pass 2 it is --
+// pass 1 is the same lane code in every form and family, the families differ in pass 2).  Returns false when the ordinary flush has to do it.
+bool flush_from_queue(ow_context *c, int left, ow_status *out) {
+    ow_context::Lookahead &la = c->la;
+    constexpr int kRing = ow_context::Lookahead::kMaxAhead;
+    if (!la.armed || la.count != 1 || la.mode != 2 || left < 1 || left > kRing || la.queued < left) return false;
+    if (lookahead_mode(c, 1) != 2 || batch_size(c, left) != left) return false;  // (timing, fault injection, no merging, pinned families: the ordinary path)
+    const int g0 = la.group[la.head];
+    for (int j = 0; j < left; ++j) {  // launch slot j = cascade left - 1 - j, the order ow_process would have taken them = the queue's order
+        const int e = (la.head + j) % kRing, cascade = left - 1 - j;
+        const ow_cascade_params &p = c->pass_parameters[cascade];
+        const float t = (float)p.time;
+        if (p.should_generate_spectrum || validate_record(p, cascade) != OW_OK || la.cascade[e][0] != cascade || std::memcmp(&t, &la.time[e][0], 4) != 0 ||
+            p.tile_length[0] != la.tile_x[e][0] || p.tile_length[1] != la.tile_y[e][0] || la.group[e] != g0 + j)  // (consecutive slots: no wrap of the ring)
+            return false;
+    }
+    ow::FrameArgs args;
+    std::memset(&args, 0, sizeof(args));
+    for (int j = 0; j < left; ++j) {
+        const int cascade = left - 1 - j;
+        const ow_cascade_params &p = c->pass_parameters[cascade];
+        c->maps_faulted &= ~(1u << cascade);
+        c->enqueued_since_sync |= 1u << cascade;
+        record_frame_constants(c, cascade, p);
+        args.c[j] = frame_of(p, cascade);
+    }
+    c->last_args = args;
+    c->last_count = left;
+    c->last_family = ow::kernel_family(c->n, left, c->kernel_mode);
+    for (int &sl : c->slot_of) sl = -1;
+    ow::DeviceBuffers b = c->buf;  // the batch's intermediate starts at scratch slot g0 (a queue entry of one cascade = one slot)
+    const size_t pl = (size_t)c->n * c->n;
+    b.T += (size_t)g0 * pl * ow::kLayers;
+    b.pcol += (size_t)g0 * c->n;
+    b.rrow += (size_t)g0 * c->n * 4;
+    const hipError_t e = ow::launch_pass2(c->n, left, c->kernel_mode, args, b, c->stream);
+    if (e != hipSuccess) {
+        la.armed = false;
+        la.queued = 0;
+        *out = fail(OW_ERR_HIP, "flush from the look-ahead queue failed: %s", hipGetErrorString(e));
+        return true;
+    }
+    la.hits += (uint64_t)left;
+    la.head = (la.head + left) % kRing;
+    la.queued -= left;
+    la.armed = la.queued > 0;
+    la.cur_group = g0 + left - 1;
+    *out = OW_OK;
+    return true;
 }
 
 ow_status check_cascade(const ow_context *c, int cascade) {
@@ -992,15 +1048,8 @@ ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, in
         // nothing of `params` has been touched yet, so the call can simply be repeated.)
         c->pass_num_cascades_remaining = 0;
         ow_status st = OW_OK;
-        if (c->la.armed && c->la.queued > 0 && c->la.count == 1) {
-            // their pass 1 may be waiting in the queue (computed ahead for the ow_process calls that never came): one cascade at a time, in the
-            // order those calls would have taken them -- each is checked like any ow_process, a miss takes the ordinary two launches.  (Cascades
-            // are independent: the order of the flush does not show in any result.)
-            for (int i = left - 1; i >= 0 && st == OW_OK; --i)
-                if (!lookahead_process(c, i, &st)) st = enqueue(c, c->pass_parameters, &i, 1);
-        } else {
-            st = enqueue(c, c->pass_parameters, idx, left);
-        }
+        // (their pass 1 may be waiting in the queue, computed ahead for the ow_process calls that never came: then the flush is one pass-2 launch)
+        if (!flush_from_queue(c, left, &st)) st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
     // the caller's cadence (look-ahead: lookahead_tick / lookahead_process).  "The same delta" tolerates a nanosecond: a fixed-step scene behind

@@ -54,7 +54,7 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     if not flags:  # measured by the run itself, and close to the design bytes (72.7 B/texel at the memory side against 72)
         assert rf["traffic_source"].startswith("measured by this run"), rf.get("traffic_measurement_failed")
-        assert 0.9 < rf["traffic"] / rf["bytes_per_launch"] < 1.15 and rf["traffic_detail"]["full_launch_equivalents"] == 80
+        assert 0.9 < rf["traffic"] / rf["bytes_per_launch"] < 1.15 and rf["traffic_detail"]["full_launch_equivalents"] == 81   # (81 ticks, every launch a full pair: the seamless stream of round 5)
     else:
         assert rf["traffic"] is None or "NOT measured by this run" in rf["traffic_source"]
     # round 5: the four ways of driving the boundary are timed interleaved, with the clocks in the record; the scene's own cadence and -- on the

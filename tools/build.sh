@@ -8,7 +8,7 @@ hipcc $F tools/kbench.hip -o tools/kbench &
 hipcc $F -DKBENCH_N=2048 tools/kbench.hip -o tools/kbench_2048 &
 hipcc $F -I tools -DKS_N=256 tools/kbench_small.hip -o tools/kbench_small_256 &
 hipcc $F -I tools -DKS_N=512 tools/kbench_small.hip -o tools/kbench_small_512 &
-hipcc $F -DOW_PAIR_SLIM_ARGS=0 tools/kbench_2048pair.hip -o tools/kbench_2048pair &   # (drives the pair kernel with the tick groups' argument structs)
+hipcc $F tools/kbench_2048pair.hip -o tools/kbench_2048pair &
 hipcc $F tools/cvtcheck.hip -o tools/cvtcheck &
 wait
 ls -la tools/kbench tools/kbench_2048 tools/kbench_small_256 tools/kbench_small_512

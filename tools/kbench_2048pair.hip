@@ -60,14 +60,19 @@ int main(int argc, char **argv) {
     printf("  k_pass1c_split<4 rows> alone : %8.2f\n", time_it(p1, iters * C, s));
     printf("  k_pass2c alone               : %8.2f\n", time_it(p2, iters * C, s));
     printf("  one launch per pass          : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
-    TickGroupArgs g{};
-    g.pair_compact = 1; g.slots2 = g.slots1 = 1; g.d2 = g.d1 = 1; g.n2 = g.n1 = N / 4;  // 8-wave blocks of both kinds
-    auto pair = [&](int i) {  // pass 2 of cascade i - 1 (scratch slot (i - 1) & 1), pass 1 of cascade i (scratch slot i & 1)
-        TickGroupArgs h = g;
-        h.first2 = (i + C - 1) % C; h.first1 = i % C; h.tbase2[0] = (i + 1) & 1; h.tbase1[0] = i & 1;
-        for (int k = 0; k < C; ++k) h.time1[0][k] = args.c[k].time;
-        hipLaunchKernelGGL((k_tick_pair_c_split<N, false>), dim3(h.n2 + h.n1), dim3(PT), 0, s, buf, args, h, (Stamp *)nullptr);
+    PairArgs g{};
+    g.n2 = g.n1 = N / 4;  // 8-wave blocks of both kinds
+    for (int k = 0; k < kMaxCascades; ++k) {
+        const CascadeFrame &cf = args.c[k];
+        g.c[k] = PairFrame{cf.tile_x, cf.tile_y, cf.whitecap, cf.foam_grow_rate, cf.foam_decay, cf.cascade};
+        g.time1[k] = cf.time;
+    }
+    auto pair_args = [&](int i) {  // pass 2 of cascade i - 1 (scratch slot (i - 1) & 1), pass 1 of cascade i (scratch slot i & 1)
+        PairArgs h = g;
+        h.first2 = (i + C - 1) % C; h.first1 = i % C; h.tbase2 = (i + 1) & 1; h.tbase1 = i & 1;
+        return h;
     };
+    auto pair = [&](int i) { hipLaunchKernelGGL((k_tick_pair_c_split<N, false>), dim3(g.n2 + g.n1), dim3(PT), 0, s, buf, pair_args(i), (Stamp *)nullptr); };
     printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
     printf("  one launch per pass (again)  : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
     printf("  k_tick_pair_c_split (again)  : %8.2f\n", time_it(pair, iters * C, s));
@@ -102,9 +107,7 @@ int main(int argc, char **argv) {
     }
     {
         for (int i = 0; i < 8; ++i) {
-            TickGroupArgs h = g; h.first2 = (i + C - 1) % C; h.first1 = i % C; h.tbase2[0] = (i + 1) & 1; h.tbase1[0] = i & 1;
-            for (int k = 0; k < C; ++k) h.time1[0][k] = args.c[k].time;
-            hipLaunchKernelGGL((k_tick_pair_c_split<N, false, true>), dim3(h.n2 + h.n1), dim3(PT), 0, s, buf, args, h, st);
+            hipLaunchKernelGGL((k_tick_pair_c_split<N, false, true>), dim3(g.n2 + g.n1), dim3(PT), 0, s, buf, pair_args(i), st);
         }
         CK(hipStreamSynchronize(s));
         std::vector<Stamp> h((size_t)(g.n2 + g.n1) * W2); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
