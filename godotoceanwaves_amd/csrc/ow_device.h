@@ -902,41 +902,43 @@ struct Pass1 {
     static OW_DEV void modulate(cplx *h, const cplx *a, const cplx *b, const float *om, float time) {
 #if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 1)
         if constexpr (kPairwise) {
-        // Texels j and j + 1 together, every value in "one texel per half" layout: nothing has to be shuffled between the steps.
-        //   reduction (sincos_phase's Cody-Waite, three steps)  ->  the two polynomials of sincos_phase, each for both texels  ->  sign (-1)^n
-        //   ->  h = (a + b) (c, s) combined as  h.re = fma(pp.re, c, -(pp.im s)),  h.im = fma(qq.im, c, qq.re s)  with pp = a + b, qq = a - b:
-        // exactly the operations (and the two fused products) the one-texel form compiles to -- bit-identical (scripts/hash_maps.py).
+            // Texels j and j + 1 together, every value in "one texel per half" layout, so that nothing has to be shuffled between the steps:
+            //   sincos_phase's Cody-Waite reduction  ->  its two polynomials, each for both texels  ->  the sign (-1)^n  ->  per texel
+            //   h.re = fma(pp.re, c, -(pp.im s)),  h.im = fma(qq.im, c, qq.re s)   with pp = a + b, qq = a - b, (c, s) = exp(i omega t):
+            // exactly the operations -- the two fused products included -- that the one-texel form below compiles to.
 #pragma unroll
-        for (int j = 0; j < P; j += 2) {
-            const cplx ph = cplx{om[j], om[j + 1]} * cplx{time, time};  // the FP32-rounded products (spectrum_modulate.glsl:65): only a multiply and explicit fmas consume them
-            const cplx q = ph * cplx{0.318309886183790672f, 0.318309886183790672f};
-            const cplx n = cplx{__builtin_rintf(q.x), __builtin_rintf(q.y)};
-            cplx r = __builtin_elementwise_fma(-n, cplx{3.140625f, 3.140625f}, ph);
-            r = __builtin_elementwise_fma(-n, cplx{9.67502593994140625e-4f, 9.67502593994140625e-4f}, r);
-            r = __builtin_elementwise_fma(-n, cplx{1.509957990978376432e-7f, 1.509957990978376432e-7f}, r);
-            const cplx z = r * r;
-            cplx ps = cplx{2.6343420813645935e-06f, 2.6343420813645935e-06f};
-            ps = __builtin_elementwise_fma(ps, z, cplx{-0.00019822614558506757f, -0.00019822614558506757f});
-            ps = __builtin_elementwise_fma(ps, z, cplx{0.008333241567015648f, 0.008333241567015648f});
-            ps = __builtin_elementwise_fma(ps, z, cplx{-0.1666666567325592f, -0.1666666567325592f});
-            const cplx sn = __builtin_elementwise_fma(ps * z, r, r);
-            cplx pc = cplx{-2.654252000411361e-07f, -2.654252000411361e-07f};
-            pc = __builtin_elementwise_fma(pc, z, cplx{2.478597525623627e-05f, 2.478597525623627e-05f});
-            pc = __builtin_elementwise_fma(pc, z, cplx{-0.0013888811226934195f, -0.0013888811226934195f});
-            pc = __builtin_elementwise_fma(pc, z, cplx{0.0416666679084301f, 0.0416666679084301f});
-            const cplx cs = __builtin_elementwise_fma(pc * z, z, __builtin_elementwise_fma(cplx{-0.5f, -0.5f}, z, cplx{1.0f, 1.0f}));
+            for (int j = 0; j < P; j += 2) {
+                // (the FP32-rounded products omega * t of spectrum_modulate.glsl:65: only a multiply and explicit fmas consume them)
+                const cplx ph = cplx{om[j], om[j + 1]} * cplx{time, time};
+                const cplx q = ph * cplx{0.318309886183790672f, 0.318309886183790672f};
+                const cplx n = cplx{__builtin_rintf(q.x), __builtin_rintf(q.y)};
+                cplx r = __builtin_elementwise_fma(-n, cplx{3.140625f, 3.140625f}, ph);
+                r = __builtin_elementwise_fma(-n, cplx{9.67502593994140625e-4f, 9.67502593994140625e-4f}, r);
+                r = __builtin_elementwise_fma(-n, cplx{1.509957990978376432e-7f, 1.509957990978376432e-7f}, r);
+                const cplx z = r * r;
+                cplx ps = cplx{2.6343420813645935e-06f, 2.6343420813645935e-06f};
+                ps = __builtin_elementwise_fma(ps, z, cplx{-0.00019822614558506757f, -0.00019822614558506757f});
+                ps = __builtin_elementwise_fma(ps, z, cplx{0.008333241567015648f, 0.008333241567015648f});
+                ps = __builtin_elementwise_fma(ps, z, cplx{-0.1666666567325592f, -0.1666666567325592f});
+                const cplx sn = __builtin_elementwise_fma(ps * z, r, r);
+                cplx pc = cplx{-2.654252000411361e-07f, -2.654252000411361e-07f};
+                pc = __builtin_elementwise_fma(pc, z, cplx{2.478597525623627e-05f, 2.478597525623627e-05f});
+                pc = __builtin_elementwise_fma(pc, z, cplx{-0.0013888811226934195f, -0.0013888811226934195f});
+                pc = __builtin_elementwise_fma(pc, z, cplx{0.0416666679084301f, 0.0416666679084301f});
+                const cplx cs = __builtin_elementwise_fma(pc * z, z, __builtin_elementwise_fma(cplx{-0.5f, -0.5f}, z, cplx{1.0f, 1.0f}));
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const uint32_t flip = (uint32_t)(int)(e ? n.y : n.x) << 31;  // (-1)^n as a sign bit
-                const float se = e ? sn.y : sn.x, ce = e ? cs.y : cs.x;
-                const float s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, se) ^ flip), c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, ce) ^ flip);
-                const cplx pp = cadd(a[j + e], b[j + e]), qq = csub(a[j + e], b[j + e]);
-                h[j + e] = cplx{__builtin_fmaf(pp.x, c, -mul_rn(pp.y, s)), __builtin_fmaf(qq.y, c, mul_rn(qq.x, s))};
-                opaque_inplace(h[j + e]);
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t flip = (uint32_t)(int)(e ? n.y : n.x) << 31;  // (-1)^n as a sign bit
+                    const float se = e ? sn.y : sn.x, ce = e ? cs.y : cs.x;
+                    const float s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, se) ^ flip);
+                    const float c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, ce) ^ flip);
+                    const cplx pp = cadd(a[j + e], b[j + e]), qq = csub(a[j + e], b[j + e]);
+                    h[j + e] = cplx{__builtin_fmaf(pp.x, c, -mul_rn(pp.y, s)), __builtin_fmaf(qq.y, c, mul_rn(qq.x, s))};
+                    opaque_inplace(h[j + e]);
+                }
+                if (j % 4 == 2) OW_SCHED_FENCE();
             }
-            if (j % 4 == 2) OW_SCHED_FENCE();
-        }
-        return;
+            return;
         }
 #endif
 #pragma unroll
@@ -1048,38 +1050,32 @@ struct Pass1 {
     static OW_DEV void layer_input_c(cplx *d, const cplx *h, const float *ik, int t, float ky, float dkx, Hook after_group = Hook()) {
         const float kx0 = (float)(t - N / 2) * dkx;
 #if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 4)
-        cplx cf2 = cplx{0.0f, 0.0f};
-        constexpr bool kPairCoef = kPairwise;
+        static_assert(kColSlot % 2 == 0, "the pair (kColSlot, kColSlot + 1) is computed at kColSlot");
+        cplx kx2 = cplx{0.0f, 0.0f}, ux2 = kx2, cf2 = kx2;  // kx, ux = kx / |k| and the layer's real coefficient of i h, texels j (low half) and j + 1
 #endif
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const cplx ih = cmuli(h[j]);
+            float kx, ux, coef;
 #if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 4)
-            // the real coefficient of i h for texels j, j + 1 in one go (even j computes, odd j takes the upper half); kx, ux as scalars only
-            // where the Nyquist column needs them (slot kColSlot, an even slot)
-            static_assert(kColSlot % 2 == 0, "the pair (kColSlot, kColSlot + 1) is computed at kColSlot");
-            cplx kx2 = cplx{0.0f, 0.0f}, ux2 = kx2;
-            if (!kPairCoef) {
-                const float kx1 = kx_of(j, kx0, dkx), ux1 = kx1 * ik[j];
-                kx2 = cplx{kx1, 0.0f}, ux2 = cplx{ux1, 0.0f};
-                const float c1 = (L == 0) ? __builtin_fmaf(ky, ik[j], 1.0f) : (L == 1) ? ux1 : __builtin_fmaf(-kx1, ux1, kx1);
-                cf2 = cplx{c1, c1};
-            } else if (j % 2 == 0) {
-                kx2 = kx_pair(j, kx0, dkx);
-                const cplx ikp = cplx{ik[j], ik[j + 1]};
-                ux2 = kx2 * ikp;
-                cf2 = ux2;                                                                                       // L == 1
-                if (L == 0) cf2 = __builtin_elementwise_fma(cplx{ky, ky}, ikp, cplx{1.0f, 1.0f});              // 1 + ky / |k| (one fma, as the scalar form contracts)
-                if (L == 2) cf2 = __builtin_elementwise_fma(-kx2, ux2, kx2);
-            }
-            const float kx = kx2.x, ux = ux2.x;  // (read at j == kColSlot only)
-            d[j] = cscale(ih, (j % 2 == 0) ? cf2.x : cf2.y);
-#else
-            const float kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
-            if (L == 0) d[j] = cscale(ih, 1.0f + ky * ik[j]);
-            if (L == 1) d[j] = cscale(ih, ux);
-            if (L == 2) d[j] = cscale(ih, __builtin_fmaf(-kx, ux, kx));
+            if constexpr (kPairwise) {
+                if (j % 2 == 0) {  // the pair's arithmetic in packed instructions; the odd texel takes the upper halves
+                    kx2 = kx_pair(j, kx0, dkx);
+                    const cplx ikp = cplx{ik[j], ik[j + 1]};
+                    ux2 = kx2 * ikp;
+                    cf2 = L == 0   ? __builtin_elementwise_fma(cplx{ky, ky}, ikp, cplx{1.0f, 1.0f})  // 1 + ky / |k|: ONE fma, as the one-texel form contracts
+                          : L == 1 ? ux2
+                                   : __builtin_elementwise_fma(-kx2, ux2, kx2);
+                }
+                kx = kx2.x, ux = ux2.x;  // (read at j == kColSlot only: an even slot)
+                coef = (j % 2 == 0) ? cf2.x : cf2.y;
+            } else
 #endif
+            {
+                kx = kx_of(j, kx0, dkx), ux = kx * ik[j];
+                coef = L == 0 ? __builtin_fmaf(ky, ik[j], 1.0f) : L == 1 ? ux : __builtin_fmaf(-kx, ux, kx);
+            }
+            d[j] = cscale(ih, coef);
             if (j == kColSlot && L > 0) {
                 const cplx line = (L == 1) ? cplx{0.0f, 0.0f} : cadd(cscale(h[j], ux * ky), cscale(ih, -(ux * kx)));
                 d[j] = cplx{t == 0 ? line.x : d[j].x, t == 0 ? line.y : d[j].y};
