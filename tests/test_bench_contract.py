@@ -114,3 +114,63 @@ def test_two_rank_rehearsal_carries_the_scaling_references(tmp_path):
     assert d["one_gpu_whole_job"]["cascades"] == 8 and d["one_gpu_whole_job"]["value"] > 0
     assert d["per_gpu_alone"]["min"] <= d["per_gpu_alone"]["value"] <= d["per_gpu_alone"]["max"]
     assert abs(d["speedup_no_gather"] - d["no_gather"]["value"] / d["per_gpu_alone"]["value"]) < 0.02 * d["speedup_no_gather"]
+
+
+def test_scene_schedule_of_the_bench_is_the_water_nodes_policy():
+    """roofline.scene_schedule drives the boundary call by call (bench.scene_frames); the calls must be exactly what the mirrored ocean node
+    (godotoceanwaves_amd.water.Water = water.gd:75-82 + the generator node's _process) issues on the same frame clock: the same update deltas,
+    bit for bit, in the same frames, one process call per frame."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from godotoceanwaves_amd.water import Water
+
+    class Calls:
+        def __init__(self):
+            self.log = []
+
+        def update(self, delta, parameters=None):
+            self.log.append(("update", delta))
+
+        def process(self):
+            self.log.append(("process",))
+
+        def _process(self, delta=0.0):   # the generator node's per-frame call
+            self.log.append(("process",))
+
+        map_size = 0
+
+        def init_gpu(self, n):
+            pass
+
+    for hz, jitter, seed in ((144, 0.05, 777), (60, 0.05, 4242), (144, 0.0, 1)):
+        frames = 400
+        a = Calls()
+        updates = bench.scene_frames(a, hz, frames, jitter, seed=seed)
+        b = Calls()
+        w = Water(generator_factory=lambda: b)
+        w.wave_generator = b
+        w._parameters = [object()]
+        state = seed
+        for _ in range(frames):
+            state = (state * 1103515245 + 12345) & 0x7FFFFFFF
+            w._process((1.0 / hz) * (1.0 + jitter * (state / 0x3FFFFFFF - 1.0)))
+        assert a.log == b.log
+        got = [e[1] for e in a.log if e[0] == "update"]
+        # (the limiter re-arms relative to the frame that fires, water.gd:80, so an update comes every ceil(frame rate / 50) frames:
+        #  every third frame at 144 Hz, every second at 60 Hz -- 48 and 30 updates per second, not 50)
+        per = -(-hz // 50)
+        assert updates == len(got) and frames / (per + 0.5) <= updates <= frames / per + 1
+        assert sum(1 for e in a.log if e[0] == "process") == frames
+        if jitter:
+            assert len(set(got[3:])) > 0.9 * len(got[3:])                                # every update a different delta
+        assert all(0.02 - 1e-12 <= d < 0.02 + 1.06 / hz for d in got)
+
+
+def test_sensor_summary_takes_medians_and_survives_missing_fields():
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.Sensors.summary([{"sclk_mhz": 2100.0, "power_w": 1300.0, "temp_mem_c": None}, None, {"sclk_mhz": 2200.0, "power_w": 1340.0, "temp_mem_c": None},
+                               {"sclk_mhz": 2150.0, "power_w": None, "temp_mem_c": None}])
+    assert s == {"samples": 3, "sclk_mhz": 2150.0, "power_w": 1320.0, "temp_mem_c": None}
+    assert bench.Sensors.summary([None, None]) is None
+    assert bench.Sensors._num({"a": "N/A", "b": [2100, 2200, "N/A", 65535], "c": 7}, "a", "b", "c") == 2150.0
