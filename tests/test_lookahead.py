@@ -289,3 +289,38 @@ def test_a_fault_reported_while_work_is_queued_ahead_drops_the_queue(n, ids):
         a.update_all(UPDATE_DELTA, pa); b.update_all(UPDATE_DELTA, pb)
     same(a, b, len(ids))
     assert a.lookahead_stats()[0] > hits1
+
+
+@pytest.mark.parametrize("n,count", [(1024, 4), (256, 4), (512, 8)])
+def test_the_scenes_cadence_update_launches_pass_1_and_the_flush_consumes_the_queue(n, count):
+    """water.gd's rate limiter never issues the same delta twice, so nothing can be guessed across updates -- but nothing has to be: ow_update itself
+    launches pass 1 of the cascades its ow_process calls will take (up to four, one launch), every ow_process is then a hit, and what an update
+    leaves unprocessed (a frame rate below cascades x update rate) is flushed by the next update from the same queue, as ONE pass-2 launch in
+    the kernel family a batch of that size takes anyway.  Bitwise the maps of a context that never merges (1024^2: a single cascade and a batch
+    of two or three fall into different families -- the flush must not change the batch's), and every cascade of every update but the first
+    (which generates the spectra) is served from work computed ahead."""
+    ids = list(range(count))
+    a, pa = make(n, ids)
+    b, pb = make(n, ids, merge=False)
+    drains = [count, count - 1, 1, 2, 0, count, 2, count - 2]
+    for k, drain in enumerate(drains):
+        d = UPDATE_DELTA * (1.0 + 0.013 * ((k * 7) % 5))   # no two updates in a row alike
+        for g, p in ((a, pa), (b, pb)):
+            g.update(d, p)
+            for _ in range(drain):
+                g._process(0.0)
+        if k in (2, 5):
+            same(a, b, count)   # reading the maps in between disturbs nothing
+    for g, p in ((a, pa), (b, pb)):   # whatever the last update left is flushed by one more, which is then drained
+        g.update(UPDATE_DELTA, p)
+        while g.pass_num_cascades_remaining:
+            g._process(0.0)
+    same(a, b, count)
+    assert [p.time for p in pa] == [p.time for p in pb]
+    hits, spec = a.lookahead_stats()
+    if count <= 4:
+        assert hits == count * len(drains)        # updates 2 .. 9: every cascade, processed or flushed; update 1 generated the spectra
+        assert spec == len(drains)                # one launch of pass 1 per update, nothing else carried work for later
+    else:
+        assert hits >= 4 * len(drains)            # (eight cascades: the queue holds four at a time; flushes of more than four take the ordinary path)
+    assert b.lookahead_stats() == (0, 0)
