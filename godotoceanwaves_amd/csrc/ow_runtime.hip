@@ -75,6 +75,11 @@ struct ow_context {
     uint32_t readback_faulted = 0;
     ow_push_constants pc_words[OW_MAX_CASCADES] = {};  // what the reference would have packed for each cascade's most recent launch (ow_get_push_constants)
     bool pc_valid[OW_MAX_CASCADES] = {};
+    // pc_words[i].spectrum are the constants layer i's RESIDENT spectrum (h0, omega) was generated from -- k_spectrum is a deterministic function
+    // of those thirteen words and the map size, so a dirty record that packs to the same words is served by what is there (spectrum_is_resident)
+    bool spectrum_resident[OW_MAX_CASCADES] = {};
+    bool always_regenerate = false;  // OW_FLAG_ALWAYS_REGENERATE_SPECTRUM: every dirty flag launches k_spectrum, as the reference does
+    uint64_t spectra_generated = 0, spectra_skipped = 0;  // ow_spectrum_stats
     // ow_update_all's adaptive look-ahead (lookahead_tick below): a pass 1 of the NEXT tick, speculated with the caller's last delta
     struct Lookahead {
         static constexpr int kMaxAhead = 4;  // ticks of pass 1 one launch may compute ahead (group kernel; the pair kernel takes one)
@@ -395,6 +400,51 @@ uint32_t f32_word(float v) {
     std::memcpy(&w, &v, 4);
     return w;
 }
+// The spectrum block of one cascade (wave_generator.gd:69-71 through render_context.gd:122-135): the launch constants and the thirteen words the
+// reference would have packed, in its order.  The exported setters clamp wind_speed and fetch_length (wave_cascade_parameters.gd:15,20:
+// max(0.0001, value), FP64); a C caller has no setter.  Everything up to the pack is FP64, as in GDScript (wave_generator.gd:69-71); the
+// narrowing is the pack's (render_context.gd:134).
+void pack_spectrum(const ow_context *c, int cascade, const ow_cascade_params &p, ow::SpectrumPC &pc, uint32_t (&w)[16]) {
+    const double wind_speed = std::max(p.wind_speed, 1e-4), fetch_length = std::max(p.fetch_length, 1e-4);
+    const double F = fetch_length * 1e3;
+    pc.seed_x = p.spectrum_seed[0];
+    pc.seed_y = p.spectrum_seed[1];
+    pc.tile_x = p.tile_length[0];
+    pc.tile_y = p.tile_length[1];
+    pc.alpha = (float)ow_jonswap_alpha(wind_speed, F);
+    pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency(wind_speed, F);
+    pc.wind_speed = (float)wind_speed;
+    pc.angle = (float)(p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
+    pc.depth = c->depth;
+    pc.swell = (float)p.swell;
+    pc.detail = (float)p.detail;
+    pc.spread = (float)p.spread;
+    std::memset(w, 0, sizeof(w));
+    w[0] = (uint32_t)pc.seed_x, w[1] = (uint32_t)pc.seed_y, w[2] = f32_word(pc.tile_x), w[3] = f32_word(pc.tile_y);
+    w[4] = f32_word(pc.alpha), w[5] = f32_word(pc.peak_frequency), w[6] = f32_word(pc.wind_speed), w[7] = f32_word(pc.angle);
+    w[8] = f32_word(pc.depth), w[9] = f32_word(pc.swell), w[10] = f32_word(pc.detail), w[11] = f32_word(pc.spread), w[12] = (uint32_t)cascade;
+}
+// A DIRTY RECORD WHOSE SPECTRUM IS ALREADY THERE.  In the reference EVERY exported setter raises should_generate_spectrum -- whitecap and
+// foam_amount included (wave_cascade_parameters.gd:32-35), which spectrum_compute.glsl never sees -- and _update re-dispatches
+// spectrum_compute with the same push constants (wave_generator.gd:68-72): a slider drag costs a spectrum per cascade per update.  The
+// spectrum is a deterministic function of the thirteen packed words (and the map size), so when a dirty record packs to exactly the words
+// layer `cascade`'s resident spectrum was generated from, regenerating would write the same bits: the flag is simply consumed.  That also
+// keeps such a record on the merged launches and the look-ahead, which step aside for a spectrum that has to be generated.
+bool spectrum_is_resident(const ow_context *c, int cascade, const ow_cascade_params &p) {
+    if (c->always_regenerate || cascade < 0 || cascade >= OW_MAX_CASCADES || !c->spectrum_resident[cascade]) return false;
+    ow::SpectrumPC pc;
+    uint32_t w[16];
+    pack_spectrum(c, cascade, p, pc, w);
+    return std::memcmp(w, c->pc_words[cascade].spectrum, sizeof(w)) == 0;
+}
+// consumes the dirty flag of armed record `cascade` if its spectrum is resident (where a record ENTERS the context: ow_update, ow_set_cascade_params)
+void settle_dirty_flag(ow_context *c, int cascade, ow_cascade_params &p) {
+    if (p.should_generate_spectrum && finite_record(p) && spectrum_is_resident(c, cascade, p)) {
+        p.should_generate_spectrum = 0;
+        ++c->spectra_skipped;
+    }
+}
+
 // render_context.gd:122-135 for the modulate and unpack blocks of one cascade (wave_generator.gd:73,85)
 void record_frame_constants(ow_context *c, int cascade, const ow_cascade_params &p) {
     ow_push_constants &w = c->pc_words[cascade];
@@ -441,30 +491,19 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
         c->enqueued_since_sync |= 1u << idx[i];
         ow_cascade_params &p = params[idx[i]];
         if (p.should_generate_spectrum) {  // :68-72
-            // the exported setters clamp these two (wave_cascade_parameters.gd:15,20: max(0.0001, value), FP64); a C caller has no setter.
-            // Everything up to the pack is FP64, as in GDScript (wave_generator.gd:69-71); the narrowing is the pack's (render_context.gd:134)
-            const double wind_speed = std::max(p.wind_speed, 1e-4), fetch_length = std::max(p.fetch_length, 1e-4);
-            const double F = fetch_length * 1e3;
             ow::SpectrumPC pc;
-            pc.seed_x = p.spectrum_seed[0];
-            pc.seed_y = p.spectrum_seed[1];
-            pc.tile_x = p.tile_length[0];
-            pc.tile_y = p.tile_length[1];
-            pc.alpha = (float)ow_jonswap_alpha(wind_speed, F);
-            pc.peak_frequency = (float)ow_jonswap_peak_angular_frequency(wind_speed, F);
-            pc.wind_speed = (float)wind_speed;
-            pc.angle = (float)(p.wind_direction * (3.14159265358979323846 / 180.0));  // deg_to_rad
-            pc.depth = c->depth;
-            pc.swell = (float)p.swell;
-            pc.detail = (float)p.detail;
-            pc.spread = (float)p.spread;
-            OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
+            uint32_t w[16];
+            pack_spectrum(c, idx[i], p, pc, w);
+            if (!c->always_regenerate && c->spectrum_resident[idx[i]] && std::memcmp(w, c->pc_words[idx[i]].spectrum, sizeof(w)) == 0) {
+                ++c->spectra_skipped;  // the same thirteen words: the resident spectrum IS what the dispatch would write (spectrum_is_resident)
+            } else {
+                c->spectrum_resident[idx[i]] = false;
+                OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
+                std::memcpy(c->pc_words[idx[i]].spectrum, w, sizeof(w));  // wave_generator.gd:71, in the reference's order
+                c->spectrum_resident[idx[i]] = true;
+                ++c->spectra_generated;
+            }
             p.should_generate_spectrum = 0;
-            uint32_t *w = c->pc_words[idx[i]].spectrum;  // wave_generator.gd:71, in the reference's order
-            std::memset(w, 0, sizeof(c->pc_words[idx[i]].spectrum));
-            w[0] = (uint32_t)pc.seed_x, w[1] = (uint32_t)pc.seed_y, w[2] = f32_word(pc.tile_x), w[3] = f32_word(pc.tile_y);
-            w[4] = f32_word(pc.alpha), w[5] = f32_word(pc.peak_frequency), w[6] = f32_word(pc.wind_speed), w[7] = f32_word(pc.angle);
-            w[8] = f32_word(pc.depth), w[9] = f32_word(pc.swell), w[10] = f32_word(pc.detail), w[11] = f32_word(pc.spread), w[12] = (uint32_t)idx[i];
         }
         record_frame_constants(c, idx[i], p);
         args.c[i] = frame_of(p, idx[i]);
@@ -940,6 +979,7 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->no_merge = (cfg->flags & OW_FLAG_NO_TICK_GROUPS) != 0;
     c->run_as_calls = (cfg->flags & OW_FLAG_RUN_AS_CALLS) != 0;
     c->run_as_reference = (cfg->flags & OW_FLAG_RUN_AS_REFERENCE_SCHEDULE) != 0;
+    c->always_regenerate = (cfg->flags & OW_FLAG_ALWAYS_REGENERATE_SPECTRUM) != 0;
     plan_tick_groups(c, cfg->flags);
     if (ensure_scratch(c, std::max(base_scratch_slots(c), lookahead_scratch_slots(c))) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
@@ -1070,6 +1110,7 @@ ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, in
         p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
         c->pass_parameters[i] = p;        // :108 -- a copy: `params` is not touched after this call returns
         p.should_generate_spectrum = 0;   // consumed: the armed copy carries it until the cascade is processed (:72)
+        settle_dirty_flag(c, i, c->pass_parameters[i]);  // ... unless the spectrum it asks for is the one that is there (spectrum_is_resident)
     }
     c->pass_count = count;
     c->pass_num_cascades_remaining = count;  // :109
@@ -1083,6 +1124,7 @@ ow_status ow_set_cascade_params(ow_context *c, int32_t index, const ow_cascade_p
     if (index < 0 || index >= c->pass_count) return fail(OW_ERR_INVALID, "index %d outside the %d records of the last ow_update", index, c->pass_count);
     if (ow_status st = validate_record(*p, index); st != OW_OK) return st;  // a refused record leaves the armed copy as it was
     c->pass_parameters[index] = *p;
+    settle_dirty_flag(c, index, c->pass_parameters[index]);
     return OW_OK;
 }
 
@@ -1120,6 +1162,13 @@ ow_status ow_lookahead_stats(const ow_context *c, uint64_t *hits, uint64_t *spec
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (hits) *hits = c->la.hits;
     if (speculated) *speculated = c->la.speculated;
+    return OW_OK;
+}
+
+ow_status ow_spectrum_stats(const ow_context *c, uint64_t *generated, uint64_t *skipped) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (generated) *generated = c->spectra_generated;
+    if (skipped) *skipped = c->spectra_skipped;
     return OW_OK;
 }
 

@@ -124,6 +124,9 @@ typedef struct ow_config {
 #define OW_FLAG_GROUP_P1_COMPACT 0x200u
 #define OW_FLAG_GROUP_P2_PLAIN 0x400u
 #define OW_FLAG_GROUP_P2_PIPE 0x800u
+/* Tests / measurements: every raised should_generate_spectrum launches the spectrum kernel, as the reference's _update does
+ * (wave_generator.gd:68-72), even when the record packs to the very constants the resident spectrum was generated from (ow_spectrum_stats). */
+#define OW_FLAG_ALWAYS_REGENERATE_SPECTRUM 0x1000u
 
 typedef struct ow_context ow_context;
 
@@ -193,6 +196,17 @@ ow_status ow_process(ow_context *ctx);
  * ow_lookahead_stats: calls served from work computed ahead, launches that carried some. */
 ow_status ow_update_all(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count);
 ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *speculated);
+
+/* The dirty flag and the spectrum that is already there.  In the reference EVERY exported setter of WaveCascadeParameters raises
+ * should_generate_spectrum -- `whitecap` and `foam_amount` included (wave_cascade_parameters.gd:32-35), which spectrum_compute.glsl never
+ * reads -- and the next _update re-dispatches spectrum_compute with the SAME push constants (wave_generator.gd:68-72).  The spectrum is a
+ * deterministic function of the thirteen packed words of that block (ow_get_push_constants: spectrum) and the map size, so a dirty record
+ * that packs to exactly the words layer i's resident spectrum was generated from is served by what is there: the flag is consumed where the
+ * record enters the context (ow_update / ow_update_all / ow_run, ow_set_cascade_params), no spectrum kernel is launched, and the record stays
+ * on the merged launches and the look-ahead (which step aside for a spectrum that has to be generated).  Bit-identical maps; a whitecap
+ * slider dragged at 50 updates per second no longer costs a spectrum per cascade per update.  ow_get_cascade_params then shows the flag
+ * already cleared.  ow_spectrum_stats: spectrum kernels launched by this context, and dirty flags consumed without one. */
+ow_status ow_spectrum_stats(const ow_context *ctx, uint64_t *generated, uint64_t *skipped);
 
 /* `frames` consecutive ow_update_all() ticks with the same delta, enqueued back to back (the reference's
  * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times. */

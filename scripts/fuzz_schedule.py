@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA  # noqa: E402
 
-CONFIGS = [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8), (2048, 1)]
+# every launch shape of ow_run: tick groups (256^2, 512^2 x 2, 1024^2 x 1), the seamless single-batch pair stream (512^2 x 8, 1024^2 x 3, the headline
+# 1024^2 x 4, 2048^2 x 1) and the multi-batch cascade-major stream (1024^2 x 8 = 4 + 4, 2048^2 x 2 = 1 + 1), whose 64-tick blocks the long runs below cross
+CONFIGS = [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8), (2048, 1), (1024, 4), (1024, 8), (2048, 2)]
 DELTAS = (UPDATE_DELTA, UPDATE_DELTA, UPDATE_DELTA, UPDATE_DELTA, 0.03, 1.0 / 60.0)
 
 
@@ -69,6 +71,8 @@ def schedule(n, count, seed, ops=60):
                     both(f"update({d:.5f}) + {drain} x process", reference)
             elif r < 0.78:
                 frames = rng.randint(1, 7)
+                if rng.random() < 0.12:   # a run that crosses a 64-tick block of the cascade-major stream / several deep tick groups
+                    frames = rng.randint(60, 70)
                 d = delta
                 both(f"run({frames})", lambda g, p: g.run(d, p, frames))
             elif r < 0.84:

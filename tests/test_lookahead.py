@@ -243,7 +243,7 @@ def test_run_as_reference_schedule_is_update_plus_one_process_per_cascade():
     assert hits == 29 * 4 and a.pass_num_cascades_remaining == 0   # (all but the first update's, which generates the spectra)
 
 
-@pytest.mark.parametrize("n,count", [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8), (2048, 1)])  # = fuzz_schedule.CONFIGS
+@pytest.mark.parametrize("n,count", [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8), (2048, 1), (1024, 4), (1024, 8), (2048, 2)])  # = fuzz_schedule.CONFIGS
 def test_random_schedules_hold_the_bits_of_a_context_that_never_merges(n, count):
     """scripts/fuzz_schedule.py: random sequences of update_all (repeating and changing deltas), update + some or all of its process calls, short
     runs, live edits, fewer cascades, restored foam -- every merged launch shape against OW_FLAG_NO_TICK_GROUPS, bit for bit"""
@@ -252,9 +252,9 @@ def test_random_schedules_hold_the_bits_of_a_context_that_never_merges(n, count)
     spec = importlib.util.spec_from_file_location("fuzz_schedule", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_schedule.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    assert (n, count) in fz.CONFIGS
+    assert (n, count) in fz.CONFIGS and len(fz.CONFIGS) == 11
     served = 0
-    for seed in (11, 12, 13, 14, 15):   # 8 configurations x 5 fixed seeds = 40 schedules in the suite; the 320-schedule run stays a script
+    for seed in (11, 12, 13, 14, 15):   # 11 configurations x 5 fixed seeds = 55 schedules in the suite; the long run stays a script
         calls, hits = fz.schedule(n, count, seed, ops=30 if n >= 2048 else 40)
         served += hits
     assert served > 0   # (the schedules do reach the look-ahead)
