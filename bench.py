@@ -35,8 +35,10 @@
            `roofline.scene_schedule`: the reference scene's real cadence -- water.gd:75-82's rate limiter (50 updates/s) over 60 / 144 Hz
            frames, one ow_process per frame, leftovers flushed by the next ow_update, every update a different delta when the frame clock
            jitters -- as us per update, maps/s, look-ahead hit rate and p50 / p99 of the GPU time of one frame's calls.
-           `roofline.other_configs`: BASELINE configs C5 (2048^2 x 4, the DRAM-bound one) and C2 (256^2 x 4, 1000-frame loop) timed in the
-           same process after the headline regions (short ow_run regions, same method).
+           `roofline.other_configs`: the other ELEVEN configurations of north_star's single-GPU grid, 256^2 .. 2048^2 x {1, 4, 8} cascades, timed in
+           the same process after the headline regions (ow_run regions of exactly `steps_per_region` ticks, same method; one context at a time);
+           BASELINE configs C5 (2048^2 x 4, the DRAM-bound one) and C2 (256^2 x 4, the 1000-frame loop) with the longer budget.  The list sits at
+           the end of `roofline`; its fractions are repeated as scalars at the front (`grid_frac_x1_x4_x8`, `c5_2048x4_frac`, `c2_256x4_frac`).
            `roofline.residency` says what of the working set fits the 256 MiB Infinity Cache (so a reader knows when "HBM GB/s" is partly
            cache traffic).
   sweep  : --sweep appends one line per BASELINE configuration (256^2 x 4, 1024^2 x {1,4,8}, 2048^2 x 4), each with its
@@ -109,6 +111,8 @@ def parse():
     ap.add_argument("--secondary-time", type=float, default=0.7, help="N = 1: seconds of timed regions for each of roofline.update_all_calls / unmerged / reference_schedule "
                                                                        "(and x 1.5 for each of roofline.other_configs)")
     ap.add_argument("--no-scene", action="store_true", help="skip roofline.scene_schedule (the reference scene's rate-limited, one-cascade-per-frame cadence)")
+    ap.add_argument("--grid-time", type=float, default=0.5, help="N = 1: seconds of timed regions for each of the nine further grid configurations of roofline.other_configs")
+    ap.add_argument("--no-grid", action="store_true", help="roofline.other_configs: BASELINE configs C5 and C2 only, not the rest of north_star's 256^2 .. 2048^2 x {1, 4, 8} grid")
     ap.add_argument("--no-other-configs", action="store_true", help="skip roofline.other_configs (2048^2 x 4 and 256^2 x 4 timed in the same process after the headline)")
     ap.add_argument("--sweep", action="store_true", help="one line per BASELINE configuration, appended to --sweep-out")
     ap.add_argument("--sweep-grid", action="store_true", help="like --sweep, over the whole grid 256^2 .. 2048^2 x {1, 4, 8} cascades")
@@ -359,9 +363,15 @@ def measure_scene(torch, compute, drv, n, C, quick=False):
     return out
 
 
-def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, sensors):
-    """roofline.other_configs: one more BASELINE configuration in the same process -- spectra generated, clocks primed, then regions of EXACTLY
-    `steps` ow_run ticks between two synchronisations, repeated for ~`seconds`, median reported; bytes per texel = the compact family's 72."""
+# north_star's single-GPU reporting grid: 256^2 .. 2048^2 x {1, 4, 8}; (n, C) -> ticks per timed region (a region lasts 3 .. 50 ms)
+GRID_STEPS = {(256, 1): 1000, (256, 4): 1000, (256, 8): 1000, (512, 1): 1000, (512, 4): 400, (512, 8): 400, (1024, 1): 400, (1024, 4): 200, (1024, 8): 100,
+              (2048, 1): 200, (2048, 4): 200, (2048, 8): 100}
+
+
+def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, sensors, prime_s=0.3):
+    """roofline.other_configs: one more configuration of north_star's grid in the same process -- its own context (created and freed here: one at a
+    time), spectra generated, clocks primed for `prime_s`, then regions of EXACTLY `steps` ow_run ticks between two synchronisations, repeated for
+    ~`seconds`, median reported; bytes per texel = the compact family's 72 (68.x in tick groups: foam stays in registers between a group's ticks)."""
     from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
     gen = WaveGenerator()
     gen.map_size, gen.device_id, gen.stream = n, local_rank, compute.cuda_stream
@@ -372,7 +382,7 @@ def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, senso
         drv.run(UPDATE_DELTA, steps)
         torch.cuda.synchronize()
         tp = time.perf_counter()
-        while time.perf_counter() - tp < 0.3:
+        while time.perf_counter() - tp < prime_s:
             drv.run(UPDATE_DELTA, steps)
             torch.cuda.synchronize()
         samples, smp = [], []
@@ -390,12 +400,28 @@ def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, senso
         kernel = MERGED_KERNEL.get(fam, fam) + ("_split" if (n == 2048 and fam == "tick_pairs_compact") else "")
         bpt = 72 - (4 * (depth - 1) / depth if fam == "tick_groups_compact" and depth > 1 else 0)  # (foam stays in registers between the ticks of a group)
         gbps = bpt * n * n * C / tick / 1e9
+        clk = Sensors.summary(smp) or {}
         return {"workload": f"{n}^2 x {C}", "steps_per_region": steps, "repeats": len(samples), "ms_per_step": round(tick * 1e3, 5),
                 "value": round(C / tick, 1), "unit": "maps/s", "kernel": kernel, "bytes_per_texel": round(bpt, 2), "achieved": round(gbps, 1),
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "ms_per_step_min_max": [round(min(samples) / steps * 1e3, 5), round(max(samples) / steps * 1e3, 5)],
-                "clocks": Sensors.summary(smp)}
+                "clocks": {k: clk[k] for k in ("sclk_mhz", "power_w") if k in clk}}
     finally:
         drv.free()
+
+
+def grid_scalars(other_configs, headline_frac):
+    """north_star's 12-configuration grid as scalars of `roofline`: the fraction of 8 TB/s per configuration (headline included) in ONE short string,
+    and the two other BASELINE configurations by name"""
+    frac = {e["workload"]: e.get("frac") for e in other_configs}
+    frac["1024^2 x 4"] = headline_frac
+    fmt = lambda v: "-" if v is None else f"{v:.2f}".lstrip("0")
+    by = {e["workload"]: e for e in other_configs}
+    out = {"grid_frac_x1_x4_x8": "; ".join(f"{gn} " + "/".join(fmt(frac.get(f"{gn}^2 x {gc}")) for gc in (1, 4, 8)) for gn in (256, 512, 1024, 2048))}
+    for key, wl in (("c5_2048x4", "2048^2 x 4"), ("c2_256x4", "256^2 x 4")):
+        if wl in by and "frac" in by[wl]:
+            out[key + "_frac"] = by[wl]["frac"]
+            out[key + "_ms_per_step"] = by[wl]["ms_per_step"]
+    return out
 
 
 def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
@@ -706,17 +732,37 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             scene = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     sync_all()
     main_drv.free()
-    # ---- other BASELINE configurations in the same process (N = 1, headline run only) ----
+    # ---- the rest of north_star's single-GPU grid in the same process (N = 1, headline run only): 256^2 .. 2048^2 x {1, 4, 8} minus the headline ----
+    # BASELINE configs C5 (2048^2 x 4, the DRAM-bound one) and C2 (256^2 x 4, the 1000-frame loop) first and with the longer budget; the other nine
+    # with ~0.5 s of regions each; one context at a time, created and freed inside measure_other_config
     other_configs = None
     if world == 1 and (n, C) == (1024, 4) and not args.no_other_configs and not args.sweep:
         other_configs = []
         del disp, norm
         torch.cuda.empty_cache()
-        for on, oc, osteps in ((2048, 4, 200), (256, 4, 1000)):   # C5: the DRAM-bound configuration; C2: the 1000-frame loop
+        todo = [(2048, 4, args.secondary_time * 1.5, 0.3), (256, 4, args.secondary_time * 1.5, 0.3)]
+        if not args.no_grid:
+            todo += [(gn, gc, args.grid_time, 0.15) for gn in (256, 512, 1024, 2048) for gc in (1, 4, 8) if (gn, gc) not in ((1024, 4), (2048, 4), (256, 4))]
+        for on, oc, osec, oprime in todo:
             try:
-                other_configs.append(measure_other_config(torch, compute, local_rank, on, oc, osteps, args.secondary_time * 1.5, sensors))
+                other_configs.append(measure_other_config(torch, compute, local_rank, on, oc, GRID_STEPS[(on, oc)], osec, sensors, prime_s=oprime))
             except Exception as e:  # noqa: BLE001
                 other_configs.append({"workload": f"{on}^2 x {oc}", "error": f"{type(e).__name__}: {str(e)[:200]}"})
+        other_configs.sort(key=lambda e: [int(v) for v in e["workload"].replace("^2 x", "").split()])
+    links = None
+    if world > 1:
+        # what lies between each rank's device and the consumer's, as the HIP runtime reports it (ow_query_link: peer access, link type, hops), so
+        # that the line says by itself whether a rank's 16 B/texel went over xGMI (the model's 153 GB/s per link), PCIe, or a staged path
+        try:
+            from godotoceanwaves_amd import _lib as _L
+            import ctypes as _C
+            lk = _L.ow_group_link()
+            _L.check(_L.load().ow_query_link(int(local_rank), 0, _C.byref(lk)))
+            mine = {"rank": rank, **lk.as_dict()}
+        except Exception as e:  # noqa: BLE001  (never the reason a scaling run fails)
+            mine = {"rank": rank, "error": str(e)[:200]}
+        links = [None] * world
+        dist.all_gather_object(links, mine)
     if rank != 0:
         return None
 
@@ -823,8 +869,9 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             # bytes this kernel must move (its family's design bytes) / its average launch duration
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
-            # (the driver's record keeps the first keys of this object: what the judge asked to see beside the headline comes first)
-            **({"other_configs": other_configs} if other_configs is not None else {}),
+            # (the driver's record keeps the first SCALAR keys of this object: the grid's fractions as scalars here, the entries themselves -- a list --
+            #  at the end of the line, where a record that keeps the tail of stdout still has them)
+            **(grid_scalars(other_configs, round(achieved / HBM_PEAK_GBPS, 4)) if other_configs is not None else {}),
             **({"scene_schedule": scene} if scene is not None else {}),
             **({"clocks": clocks} if clocks is not None else {}),
             **({"update_all_calls": {"ms_per_step": round(calls / ticks * 1e3, 5), "value": round(maps / calls, 2), "unit": "maps/s",
@@ -863,6 +910,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n} if grouped else {}),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
             "residency": res,
+            **({"other_configs": other_configs} if other_configs is not None else {}),
             "tick": {"bytes_per_texel": tick_bpt, "achieved": round(tick_moved, 1), "frac": round(tick_moved / HBM_PEAK_GBPS, 4),
                      "frac_of_copy_ceiling": round(tick_moved / COPY_CEILING_GBPS, 4),
                      "contract_gbps": round(tick_contract, 1), "frac_contract_104": round(tick_contract / HBM_PEAK_GBPS, 4)},
@@ -872,6 +920,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
         "clock_priming": priming,
     }
     if gat is not None:
+        out["links_to_root"] = links
         out["final_gather_ms"] = round(gather_ms, 3)
         out["gather_bytes"] = {"sent_per_rank": gat.bytes_sent, "received_rank0": gat.bytes_received}
         out["gather"] = {"mode": gat.mode, **({"fallback": gat.fallback} if gat.fallback else {}), "every_ticks": gather_every, "overlap": not args.no_overlap, **(cadence or {}),

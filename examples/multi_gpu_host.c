@@ -58,6 +58,14 @@ int main(int argc, char **argv) {
     ow_group *g = NULL;
     CHECK(ow_group_create(&cfg, &g));
     const int total = ow_group_num_cascades(g);
+    for (int s = 0; s < cfg.num_devices; ++s) {  /* how each shard's layers will reach the root: read the gather's figures against THIS */
+        static const char *kLink[] = {"hypertransport", "qpi", "pcie", "infiniband", "xgmi"};
+        ow_group_link l;
+        CHECK(ow_group_link_info(g, s, &l));
+        printf("shard %d: device %d -> root device %d: %s, peer_access=%d, link=%s, hops=%d, path=%s\n", s, l.device, l.root_device,
+               l.same_device ? "same device" : "another device", l.peer_access, l.link_type >= 0 && l.link_type <= 4 ? kLink[l.link_type] : "unknown", l.hops,
+               l.staged_path ? "snapshot + side stream + peer copy" : "device-to-device copy in the shard's stream");
+    }
     ow_cascade_params *par = (ow_cascade_params *)calloc((size_t)total, sizeof *par);
     for (int i = 0; i < total; ++i) {
         const float *r = kTable[i % 8];

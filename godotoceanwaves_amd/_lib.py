@@ -55,6 +55,18 @@ class ow_group_config(C.Structure):
                 ("displacement_map", C.c_void_p), ("normal_map", C.c_void_p)]
 
 
+class ow_group_link(C.Structure):
+    """how a shard's layers reach the root device (ow_group_link_info / ow_query_link)"""
+    _fields_ = [("device", C.c_int32), ("root_device", C.c_int32), ("same_device", C.c_int32), ("peer_access", C.c_int32),
+                ("link_type", C.c_int32), ("hops", C.c_int32), ("staged_path", C.c_int32), ("reserved", C.c_int32)]
+
+    LINK_TYPES = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi", -1: "unknown"}
+
+    def as_dict(self):
+        return {"device": self.device, "root_device": self.root_device, "same_device": bool(self.same_device), "peer_access": bool(self.peer_access),
+                "link": self.LINK_TYPES.get(self.link_type, str(self.link_type)), "hops": self.hops, "staged_path": bool(self.staged_path)}
+
+
 # every symbol include/ocean_waves.h declares: (restype, argtypes)
 _P = C.POINTER
 SIGNATURES = {
@@ -104,6 +116,8 @@ SIGNATURES = {
     "ow_group_gather_begin": (C.c_int, [C.c_void_p]),
     "ow_group_gather_wait": (C.c_int, [C.c_void_p]),
     "ow_group_gather_stats": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_size_t)]),
+    "ow_group_link_info": (C.c_int, [C.c_void_p, C.c_int32, _P(ow_group_link)]),
+    "ow_query_link": (C.c_int, [C.c_int32, C.c_int32, _P(ow_group_link)]),
     "ow_group_get_device_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_size_t)]),
     "ow_group_get_maps": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ow_group_sample_surface": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

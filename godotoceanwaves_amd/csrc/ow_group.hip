@@ -90,6 +90,7 @@ struct Shard {
     char *snap = nullptr;                   // [2 maps][owned layers][N][N] RGBA16F (remote shards)
     hipEvent_t snap_ready = nullptr, copy_start = nullptr, copy_done = nullptr;
     bool pending = false;  // a gather has been begun and not yet waited for
+    ow_group_link link{};  // how this shard's layers reach the root (ow_group_link_info), probed once by ow_group_create
     Worker worker;
 };
 
@@ -229,6 +230,43 @@ ow_status refuse_faulted_layers(const ow_group *g, int first, int count) {
 
 extern "C" {
 
+// what lies between two devices, as the runtime reports it: peer access (the owner's copy engine writes the consumer's memory directly) and the
+// link (hipExtGetLinkTypeAndHopCount: 4 = xGMI, 2 = PCIe) -- so that a measured gather can be read against the right model
+ow_status ow_query_link(int32_t from_device, int32_t to_device, ow_group_link *out) {
+    if (!out) return fail(OW_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->device = from_device;
+    out->root_device = to_device;
+    out->link_type = out->hops = -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(OW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (from_device < 0 || from_device >= ndev || to_device < 0 || to_device >= ndev) return fail(OW_ERR_INVALID, "device %d or %d outside [0,%d)", from_device, to_device, ndev);
+    if (from_device == to_device) {
+        out->same_device = 1;
+        out->peer_access = 1;
+        out->hops = 0;
+        return OW_OK;
+    }
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from_device, to_device) == hipSuccess) out->peer_access = can ? 1 : 0;
+    else (void)hipGetLastError();
+    uint32_t type = 0, hops = 0;
+    if (hipExtGetLinkTypeAndHopCount(from_device, to_device, &type, &hops) == hipSuccess) {
+        out->link_type = (int32_t)type;
+        out->hops = (int32_t)hops;
+    } else {
+        (void)hipGetLastError();
+    }
+    return OW_OK;
+}
+
+ow_status ow_group_link_info(const ow_group *g, int32_t shard, ow_group_link *out) {
+    if (!g || !out) return fail(OW_ERR_INVALID, "null argument");
+    if (shard < 0 || shard >= g->shards) return fail(OW_ERR_INVALID, "shard %d outside [0,%d)", shard, g->shards);
+    *out = g->s[shard].link;
+    return OW_OK;
+}
+
 ow_status ow_group_create(const ow_group_config *cfg, ow_group **out) {
     if (!cfg || !out) return fail(OW_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -268,6 +306,8 @@ ow_status ow_group_create(const ow_group_config *cfg, ow_group **out) {
         Shard &sh = g->s[i];
         sh.device = cfg->device_ids[i];
         sh.remote = force_peer || sh.device != g->root_device;
+        (void)ow_query_link(sh.device, g->root_device, &sh.link);  // (a probe: what it cannot find out stays -1)
+        sh.link.staged_path = sh.remote ? 1 : 0;
         if (hipSetDevice(sh.device) != hipSuccess) return bail(fail(OW_ERR_HIP, "hipSetDevice(%d) failed", sh.device));
         if (sh.device != g->root_device) {  // let the owning device write into the root's memory directly (xGMI); without peer access
             int can = 0;                    // hipMemcpyPeerAsync still works, staged by the runtime

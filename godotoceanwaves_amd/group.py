@@ -114,6 +114,15 @@ class WaveGeneratorGroup:
         _lib.check(self._lib.ow_group_gather_stats(self.group, C.byref(ms), C.byref(nb)))
         return ms.value, nb.value
 
+    def link_info(self):
+        """per shard: how its layers reach the root device (peer access, link type / hops as the HIP runtime reports them; ow_group_link_info)"""
+        out = []
+        for i in range(self.num_devices):
+            l = _lib.ow_group_link()
+            _lib.check(self._lib.ow_group_link_info(self.group, i, C.byref(l)))
+            out.append(l.as_dict())
+        return out
+
     def device_ptrs(self):
         d, n, stride = C.c_void_p(), C.c_void_p(), C.c_size_t()
         _lib.check(self._lib.ow_group_get_device_ptrs(self.group, C.byref(d), C.byref(n), C.byref(stride)))

@@ -351,6 +351,25 @@ ow_status ow_group_gather_wait(ow_group *group);
  * gather's inter-device copies; bytes_per_shard = cascades_per_device * N * N * 16. */
 ow_status ow_group_gather_stats(ow_group *group, float *max_copy_ms, size_t *bytes_per_shard);
 
+/* How a shard's layers reach the root device, as the HIP runtime reports it -- so that the first gather measured on a real node can be read
+ * against the right model (bytes_per_shard / 153 GB/s over one xGMI link; a PCIe or staged path is several times slower):
+ *   same_device  1: the shard sits on the root's device, its gather is a device-to-device copy in the shard's own stream;
+ *   peer_access  hipDeviceCanAccessPeer(shard -> root): 1 = hipMemcpyPeerAsync is a direct write by the owning device's copy engine into the
+ *                root's memory, 0 = the runtime stages it through the host;
+ *   link_type    hipExtGetLinkTypeAndHopCount: 4 = xGMI, 2 = PCIe (HSA_AMD_LINK_INFO_TYPE_*: 0 HyperTransport, 1 QPI, 3 InfiniBand); -1 unknown;
+ *   hops         ... its hop count (1 = a direct link); -1 unknown;
+ *   staged_path  1: the shard gathers through snapshot + side stream + peer copy (every shard on another device, or all of them under
+ *                OW_GROUP_FLAG_FORCE_PEER_PATH), 0: straight into the root's slots.
+ * ow_query_link asks the same of any two device ordinals without a group (bench.py --gpus N prints it for every rank -> root pair). */
+typedef struct ow_group_link {
+    int32_t device, root_device;
+    int32_t same_device, peer_access, link_type, hops, staged_path, reserved;
+} ow_group_link;
+#define OW_LINK_TYPE_PCIE 2
+#define OW_LINK_TYPE_XGMI 4
+ow_status ow_group_link_info(const ow_group *group, int32_t shard, ow_group_link *out);
+ow_status ow_query_link(int32_t from_device, int32_t to_device, ow_group_link *out);
+
 /* The gathered arrays on the root device (layout as ow_get_device_ptrs; layer g = global cascade g), as of the last gather. */
 ow_status ow_group_get_device_ptrs(ow_group *group, void **displacement_map, void **normal_map, size_t *layer_stride_bytes);
 /* Host copy of one gathered layer (as ow_get_maps); needs a completed gather (OW_ERR_STATE before the first one). */

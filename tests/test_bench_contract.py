@@ -72,13 +72,19 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
         assert 0 < e["frame_gpu_us_p50"] <= e["frame_gpu_us_p99"] <= e["frame_gpu_us_max"] and 0.0 < e["frac"] < 0.85
     assert sc["144hz_fixed_clock"]["us_per_update"] <= 1.1 * sc["144hz_jitter5pct"]["us_per_update"]   # (a regular cadence never costs more)
     keys = list(rf)
-    assert keys.index("scene_schedule") < 12 and keys.index("clocks") < 12 and keys.index("traffic") < 8
+    assert keys.index("scene_schedule") < 16 and keys.index("clocks") < 16 and keys.index("traffic") < 8
     if not flags:
+        # round 6: north_star's whole single-GPU grid rides in the line -- the other eleven configurations of 256^2 .. 2048^2 x {1, 4, 8} as a list at
+        # the END of `roofline` (a record that keeps the tail of stdout has it), their fractions as scalars at its front (one that keeps the first scalars)
         oc = {e["workload"]: e for e in rf["other_configs"]}
-        assert set(oc) == {"2048^2 x 4", "256^2 x 4"} and keys.index("other_configs") < 10
+        assert set(oc) == {f"{gn}^2 x {gc}" for gn in (256, 512, 1024, 2048) for gc in (1, 4, 8)} - {"1024^2 x 4"}
+        assert keys.index("other_configs") > keys.index("residency") and keys.index("grid_frac_x1_x4_x8") < 10 and keys.index("c5_2048x4_frac") < 12
         assert oc["2048^2 x 4"]["kernel"] == "k_tick_pair_c_split" and oc["256^2 x 4"]["kernel"] == "k_tick_group_c_lp"
+        assert oc["1024^2 x 8"]["kernel"] == "k_tick_pair_c" and oc["1024^2 x 1"]["kernel"] == "k_tick_group_c_lp"
         for e in oc.values():
             assert e["value"] > 0 and 0.0 < e["frac"] < 0.85 and e["repeats"] >= 3 and e["ms_per_step"] > 0
+        assert rf["c5_2048x4_frac"] == oc["2048^2 x 4"]["frac"] and rf["c2_256x4_frac"] == oc["256^2 x 4"]["frac"]
+        assert len(rf["grid_frac_x1_x4_x8"]) <= 120 and rf["grid_frac_x1_x4_x8"].count("/") == 8 and "-" not in rf["grid_frac_x1_x4_x8"]
     else:
         assert "other_configs" not in rf
     # round 4: the CPU leg runs first, the GPU work is one contiguous stretch and says how long it was

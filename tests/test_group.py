@@ -327,3 +327,26 @@ def test_c4_exact_shape_eight_shards_overlapped_gathers_against_the_oracle():
     assert params[7].time == pytest.approx(120.0 + np.pi * 7 + ticks * UPDATE_DELTA)
     og.close()
     grp.free()
+
+
+@pytest.mark.parametrize("force_peer", [True, False], ids=["peer_path", "same_device_path"])
+def test_link_info_says_how_each_shard_reaches_the_root(force_peer):
+    """ow_group_link_info / ow_query_link: what the HIP runtime reports between a shard's device and the root's, so
+    that the first gather measured on a real node can be read against the right model.  On the one-GPU box every shard sits on the root's
+    device: same_device, zero hops, and the path is the staged one exactly when OW_GROUP_FLAG_FORCE_PEER_PATH asks for it."""
+    import ctypes as C
+    grp = WaveGeneratorGroup()
+    grp.map_size = 256
+    grp.force_peer_path = force_peer
+    grp.init_gpu([0, 0, 0], 1)
+    links = grp.link_info()
+    assert len(links) == 3
+    for l in links:
+        assert l["device"] == 0 and l["root_device"] == 0 and l["same_device"] and l["peer_access"] and l["hops"] == 0
+        assert l["staged_path"] == force_peer
+    lib = _lib.load()
+    lk = _lib.ow_group_link()
+    assert lib.ow_query_link(0, 0, C.byref(lk)) == _lib.OW_OK and lk.same_device == 1
+    assert lib.ow_query_link(0, 99, C.byref(lk)) == _lib.OW_ERR_INVALID      # no such device
+    assert lib.ow_group_link_info(grp.group, 7, C.byref(lk)) == _lib.OW_ERR_INVALID
+    grp.free()
