@@ -18,6 +18,7 @@ OW_FLAG_RUN_AS_CALLS = 32
 OW_FLAG_RUN_AS_REFERENCE_SCHEDULE = 64
 OW_FLAG_GROUP_P1_LP, OW_FLAG_GROUP_P1_COMPACT, OW_FLAG_GROUP_P2_PLAIN, OW_FLAG_GROUP_P2_PIPE = 0x100, 0x200, 0x400, 0x800
 OW_FLAG_ALWAYS_REGENERATE_SPECTRUM = 0x1000
+OW_FLAG_LAZY_SCRATCH = 0x2000
 OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
 
 

@@ -137,8 +137,12 @@ OW_DEV cplx cmul_const(cplx a, float c, float sn) { return __builtin_elementwise
 // a * b, general: (a.x b.x, a.x b.y) + a.y * (-b.y, b.x).  The sign of the one half rides on the packed instruction's neg_lo modifier, which the
 // compiler does not use for a per-half sign (it emits a third instruction, a.yy * (-1, 1)); spelled out, a complex multiply is TWO packed
 // instructions -- thirty fewer per 1024-point transform (round 5).  Same products, same fma: bit-identical.
-#ifndef OW_CMUL_NEG_LO
+// (the two inline-asm spellings of this header -- this one and v_cvt_pk_f16_f32 in f2h2 -- are gfx950 encodings: any other --offload-arch takes the
+//  C forms below them instead of failing in the assembler; the library itself is built for gfx950 only, build.py)
+#if !defined(OW_CMUL_NEG_LO) && defined(__gfx950__)
 #define OW_CMUL_NEG_LO 1
+#elif !defined(OW_CMUL_NEG_LO)
+#define OW_CMUL_NEG_LO 0
 #endif
 OW_DEV cplx cmul(cplx a, cplx b) {
 #if OW_CMUL_NEG_LO
@@ -589,8 +593,10 @@ OW_DEV uint16_t f2h(float f) {
 // (v_cvt_pk_f16_f32: same rounding mode, same denormal handling as v_cvt_f16_f32 -- checked over all 2^32 inputs of either slot,
 // tools/cvtcheck.hip): one instruction where two conversions, a mask and a shift-or were four (round 5).  Spelled as the instruction for
 // f2h's reason: a C cast would fuse a producing multiply into the conversion.
-#ifndef OW_CVT_PK
+#if !defined(OW_CVT_PK) && defined(__gfx950__)
 #define OW_CVT_PK 1
+#elif !defined(OW_CVT_PK)
+#define OW_CVT_PK 0
 #endif
 OW_DEV uint32_t f2h2(float lo, float hi);
 OW_DEV float h2f(uint16_t h) {

@@ -1023,18 +1023,35 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
     ws.at(0, 0.0f);
     __shared__ __attribute__((aligned(16))) cplx lds[PG::kLdsCplx];
     // g.n2 pass-2 blocks and g.n1 pass-1 blocks (multiples of 8, either may be 0): alternate in chunks of 8 while both last
+    // (OW_PAIR_SPLIT_CHUNK_LOG2: chunks of 2^k blocks, A/B builds of tools/kbench_2048pair; both counts are then multiples of 2^k)
+#ifndef OW_PAIR_SPLIT_CHUNK_LOG2
+#define OW_PAIR_SPLIT_CHUNK_LOG2 3
+#endif
     int index = blockIdx.x;
     bool first;  // is this a pass-1 block?
     {
-        const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
+        constexpr int CL = OW_PAIR_SPLIT_CHUNK_LOG2;
+        const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> CL;
         if (index < both) {
             first = chunk & 1;
-            index = ((chunk >> 1) << 3) + (index & 7);
+            index = ((chunk >> 1) << CL) + (index & ((1 << CL) - 1));
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
         }
     }
+#ifdef OW_PAIR_EXPERIMENT
+    // tools/kbench_2048pair only (the product never defines OW_PAIR_EXPERIMENT): de-phase the two kinds of block of the launch's FIRST wave generation
+    // (blocks below OW_PAIR_EXPERIMENT: the ones resident from the start, which otherwise all issue their load bursts at the same moment) by letting one kind
+    // sleep g.pad & 255 (pass 1) / (g.pad >> 8) & 255 (pass 2) times ~1024 clocks first; bit 16: every generation; bits 17-18: s_setprio of pass 1 / pass 2
+    {
+        const int naps = first ? (g.pad & 255) : ((g.pad >> 8) & 255);
+        if (naps > 0 && ((int)blockIdx.x < OW_PAIR_EXPERIMENT || (g.pad & (1 << 16))))
+            for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16);
+        if (first && (g.pad & (1 << 17))) __builtin_amdgcn_s_setprio(1);
+        if (!first && (g.pad & (1 << 18))) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     if (!first) {  // ---- pass 2 of 4 columns ----
         cplx *tw_lds = lds;
         cplx *rows_lds = lds + PG::kP2Tw;

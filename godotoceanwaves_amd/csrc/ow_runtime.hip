@@ -92,12 +92,29 @@ struct ow_context {
         float tile_x[kMaxAhead][OW_MAX_CASCADES] = {}, tile_y[kMaxAhead][OW_MAX_CASCADES] = {};  // the tile lengths their pass 1 was computed with
         int cur_group = 0;             // group that held the most recent launch's own intermediate
         double last_delta = -1.0;      // the previous ow_update's delta, and for how many calls in a row it has been the same
+        double streak_delta = -1.0;    // ... "the same" = equal to the delta that STARTED the streak (a slowly ramping delta is not one unbroken streak)
         int streak = 0;
         int prev_run = 1;              // updates in the caller's previous run of equal deltas (1: none that says anything)
         uint64_t hits = 0, speculated = 0;
         bool hold = false;             // ow_run is about to merge the following ticks itself: its first tick must not speculate for them
         int certain = 0;               // ticks the caller GUARANTEES will follow with the same delta (ow_run's own remaining ticks): speculated without evidence
     } la;
+    // ow_run after ow_run (run_impl): what the last launch of a run computed ahead for the first launch of the NEXT run like it
+    struct RunAhead {
+        bool armed = false;          // the scratch holds that pass 1 and nothing has disturbed it since
+        int kind = 0;                // 1 = tick groups: pass 1 of `ticks` consecutive ticks of all `count` cascades; 2 = tick pairs: pass 1 of one batch, one tick
+        int count = 0;               // cascades per tick of the run that computed it
+        int D = 0, ticks = 0, pos = 0;  // kind 1: ticks per group of that run, ticks computed ahead, ring position (in ticks, mod 2 D) of the first of them
+        int batch = 0, first = 0, size = 0, parity = 0;  // kind 2: the batch (its first launch slot, its cascades) and the half of the scratch its intermediate is in
+        float time[ow::kMaxTickGroup][OW_MAX_CASCADES] = {};  // the FP32 times it was computed with, per tick (kind 2: entry 0) and launch slot
+        float tile_x[OW_MAX_CASCADES] = {}, tile_y[OW_MAX_CASCADES] = {};  // ... and the tile lengths, per launch slot
+        bool last_was_run = false;   // the most recent tick-advancing call was an ow_run (lowered by ow_update / ow_update_all / ow_process from outside a run)
+        int last_count = 0;
+        double last_delta = 0.0;
+        int run_streak = 0;          // how many runs like this one (same delta, same count) have preceded it without anything in between
+    } ra;
+    bool inside_run = false;    // ow_run is executing (its own ow_update_all calls are not "something in between")
+    int pair_dir = 0;           // direction of the next block of the cascade-major pair stream (batches 0 .. B-1 or B-1 .. 0): alternates, across runs too
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
     bool no_merge = false;      // OW_FLAG_NO_TICK_GROUPS
@@ -269,6 +286,7 @@ ow_status ensure_scratch(ow_context *c, int slots) {
     c->buf.rrow = rrow;
     c->scratch_slots = slots;
     c->la.armed = false;                 // (a speculated pass 1 went with the old buffer, too)
+    c->ra.armed = false;
     for (int &sl : c->slot_of) sl = -1;  // (the reference-layout view of the last batch's intermediate went with the old buffer)
     return OW_OK;
 }
@@ -333,6 +351,7 @@ ow_status consume_status(ow_context *c) {
     // ticks after a fault recompute their pass 1.
     c->la.armed = false;
     c->la.queued = 0;
+    c->ra.armed = false;
     for (int i = 0; i < OW_MAX_CASCADES; ++i)
         if (c->copy_pending[i]) c->readback_faulted |= 1u << i;
     return fail(OW_ERR_HIP, "device-side failure reported by a frame kernel (status 0x%x%s): the maps of the batches enqueued since "
@@ -479,6 +498,7 @@ ow::CascadeFrame frame_of(const ow_cascade_params &p, int cascade) {
 ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int count) {
     if (count <= 0) return OW_OK;
     c->la.armed = false;  // this path uses the scratch intermediate from slot 0 on: a speculated pass 1 (lookahead_tick) does not survive it
+    c->ra.armed = false;  // ... nor does what a run computed ahead for the next run
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     // everything is validated before anything is launched: a bad record must not leave the batch half enqueued
@@ -630,6 +650,7 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
         la.armed = false;
         return false;
     }
+    c->ra.armed = false;  // (the launches below write the scratch: whatever a run had computed ahead for a next run is gone)
     ow::FrameArgs args;
     std::memset(&args, 0, sizeof(args));
     for (int i = 0; i < count; ++i) {
@@ -778,9 +799,21 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
 void lookahead_prearm(ow_context *c) {
     ow_context::Lookahead &la = c->la;
     constexpr int kRing = ow_context::Lookahead::kMaxAhead;
-    if (la.armed && la.queued > 0) return;  // work computed ahead is waiting already (a regular cadence: the previous update's last ow_process guessed right or wrong -- its check comes with the call)
     if (lookahead_mode(c, 1) != 2) return;  // the group kernel's form only (a cascade of the layer-parallel compact family: <= 1 Mi texels)
     const int idx = c->pass_num_cascades_remaining - 1;
+    if (la.armed && la.queued > 0) {
+        // Work computed ahead is waiting already.  If its head is what the first ow_process of this update will ask for (a regular cadence: the previous
+        // update's last ow_process guessed right), leave it.  If it cannot hit -- pair-kernel entries left by ow_update_all, a guess made with another
+        // delta -- that call would miss, launch a lone pass 1 and refill: the round-4 path.  Drop the stale queue and pre-arm instead.
+        const ow_cascade_params &p = c->pass_parameters[idx];
+        const float t = (float)p.time;
+        const int h = la.head;
+        if (la.count == 1 && la.mode == 2 && la.cascade[h][0] == idx && std::memcmp(&t, &la.time[h][0], 4) == 0 && p.tile_length[0] == la.tile_x[h][0] &&
+            p.tile_length[1] == la.tile_y[h][0])
+            return;
+        la.armed = false;
+        la.queued = 0;
+    }
     int depth = std::min(idx + 1, std::min(kRing, c->ahead_depth));
     for (int k = 0; k < depth; ++k) {
         const ow_cascade_params &p = c->pass_parameters[idx - k];
@@ -789,6 +822,7 @@ void lookahead_prearm(ow_context *c) {
     if (depth < 1) return;
     const int groups = kRing + 1, stride = 1;
     if (ensure_scratch(c, groups * stride) != OW_OK) return;
+    c->ra.armed = false;
     const int cur = 0;  // (nothing is queued and everything launched so far precedes this launch in stream order: any group will do -- the entries then
                         //  sit in groups 1 .. depth, consecutive scratch slots without a wrap of the ring, which is what flush_from_queue needs)
     ow::FrameArgs args;
@@ -981,7 +1015,10 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->run_as_reference = (cfg->flags & OW_FLAG_RUN_AS_REFERENCE_SCHEDULE) != 0;
     c->always_regenerate = (cfg->flags & OW_FLAG_ALWAYS_REGENERATE_SPECTRUM) != 0;
     plan_tick_groups(c, cfg->flags);
-    if (ensure_scratch(c, std::max(base_scratch_slots(c), lookahead_scratch_slots(c))) != OW_OK) return bail(OW_ERR_NOMEM);
+    // (OW_FLAG_LAZY_SCRATCH: one batch now, the look-ahead's share on its first use -- a context that is only ever driven through ow_run's tick groups,
+    //  or one of many shards on a device, need not hold it)
+    const bool lazy_scratch = (cfg->flags & OW_FLAG_LAZY_SCRATCH) != 0;
+    if (ensure_scratch(c, lazy_scratch ? base_scratch_slots(c) : std::max(base_scratch_slots(c), lookahead_scratch_slots(c))) != OW_OK) return bail(OW_ERR_NOMEM);
     if (cfg->displacement_map) {
         c->buf.disp = (ow::u16x4 *)cfg->displacement_map;
     } else {
@@ -1068,6 +1105,20 @@ void ow_destroy(ow_context *c) {
 
 namespace {
 ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, int32_t count, bool process_calls_follow);
+// The caller's cadence (look-ahead: lookahead_tick / lookahead_process).  "The same delta" tolerates a nanosecond: a fixed-step scene behind
+// water.gd's rate limiter (:78, target + (time - next_update_time)) issues deltas that are equal up to the rounding noise of its FP64 clock,
+// and what has to repeat for a hit is the FP32-narrowed TIME (ulp 7.6e-6 s from t = 64 s on), which the hit check compares bit for bit anyway.
+// (measured against the delta that STARTED the streak, so that drift does not accumulate unnoticed, and relative for large deltas.)
+void note_cadence(ow_context *c, double delta) {
+    if (std::fabs(delta - c->la.streak_delta) <= 1e-9 * std::max(1.0, std::fabs(c->la.streak_delta))) {
+        if (c->la.streak < (1 << 30)) ++c->la.streak;
+    } else {
+        c->la.prev_run = c->la.streak + 1;
+        c->la.streak = 0;
+        c->la.streak_delta = delta;
+    }
+    c->la.last_delta = delta;
+}
 }
 ow_status ow_update(ow_context *c, double delta, ow_cascade_params *params, int32_t count) { return update_impl(c, delta, params, count, true); }
 namespace {
@@ -1092,16 +1143,8 @@ ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, in
         if (!flush_from_queue(c, left, &st)) st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
-    // the caller's cadence (look-ahead: lookahead_tick / lookahead_process).  "The same delta" tolerates a nanosecond: a fixed-step scene behind
-    // water.gd's rate limiter (:78, target + (time - next_update_time)) issues deltas that are equal up to the rounding noise of its FP64 clock,
-    // and what has to repeat for a hit is the FP32-narrowed TIME (ulp 7.6e-6 s from t = 64 s on), which the hit check compares bit for bit anyway
-    if (std::fabs(delta - c->la.last_delta) <= 1e-9) {
-        if (c->la.streak < (1 << 30)) ++c->la.streak;
-    } else {
-        c->la.prev_run = c->la.streak + 1;
-        c->la.streak = 0;
-    }
-    c->la.last_delta = delta;
+    note_cadence(c, delta);
+    if (!c->inside_run) c->ra.last_was_run = false;  // (a tick issued by the caller itself: the next ow_run does not "follow a run")
     for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
         ow_cascade_params &p = params[i];
         p.time += delta;
@@ -1139,6 +1182,7 @@ ow_status ow_process(ow_context *c) {  // :56-63
     if (!c) return fail(OW_ERR_INVALID, "null context");
     if (c->pass_num_cascades_remaining == 0) return OW_OK;
     OW_HIP(hipSetDevice(c->device));
+    if (!c->inside_run) c->ra.last_was_run = false;
     const int idx = c->pass_num_cascades_remaining - 1;
     ow_status st = OW_OK;
     if (!lookahead_process(c, idx, &st)) st = enqueue(c, c->pass_parameters, &idx, 1);
@@ -1256,13 +1300,75 @@ void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_para
     for (int &sl : c->slot_of) sl = -1;  // (no reference-layout intermediate to inspect after such a run)
 }
 
-// `ticks` >= 2 consecutive ow_update_all() ticks in groups of D = group_depth:
-//   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group];  tick t uses scratch slots (t mod 2D) * count ...
-ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D) {
+// RUNS THAT FOLLOW RUNS (round 6).  A host that calls ow_run again and again -- bench.py's timed regions, a headless simulation in chunks -- used to
+// pay, per call, an ordinary first tick (flush, spectra, validation: two launches per batch, nothing merged) and two half-filled launches at the ends
+// of the merged stream (pass 1 of the first group / batch alone, pass 2 of the last alone): 195 us at 1024^2 x 8, 268 at 2048^2 x 4, 42 at 256^2 x 4
+// (profiles/r05_run_overhead.txt).  Now the LAST launch of a run that itself followed a run with the same delta and cascade count also carries pass 1
+// of what the NEXT such run would start with -- the first tick group (times + delta, + 2 delta, ..: as many ticks as this run's first group had) or,
+// in the cascade-major pair stream, the next tick of the batch the run ended on -- and the next run checks it exactly like a look-ahead hit (count,
+// every FP32 time and tile length bit for bit, nothing armed, no spectrum to generate, nothing else has touched the scratch) and starts in the middle
+// of the stream: every launch of back-to-back runs is a full one.  A miss costs what a run cost before.  The first run after anything else never
+// speculates, so a one-shot caller (one ow_run, then a readback) leaves nothing in the queue.  Bit-identical either way (the same item bodies).
+// The pair stream also turns round at every block: batch order 0 .. B-1, then B-1 .. 0, ..., across runs as well (pair_dir) -- the batch that ends a
+// block (a run) is the one the next starts with, still warm in the Infinity Cache (round 5's trace: the first launch of a 20-tick run at 1024^2 x 8,
+// pass 1 of the batch the previous run had left cold, 55 us instead of 28).
+// 0 = the run starts the ordinary way; otherwise what tick_groups_usable returns, and c->ra holds pass 1 of this run's first group / batch
+int run_resume_usable(ow_context *c, double delta, const ow_cascade_params *params, int count, int frames) {
+    const ow_context::RunAhead &ra = c->ra;
+    if (!ra.armed || ra.count != count || frames < 1 || c->timing != 0 || c->inject_fault || c->pass_num_cascades_remaining != 0) return 0;
+    if (ow::validate_records(params, count, delta) != OW_OK) return 0;  // (the ordinary path reports it)
+    ow_cascade_params tmp[OW_MAX_CASCADES];
+    for (int i = 0; i < count; ++i) {
+        tmp[i] = params[i];
+        if (tmp[i].should_generate_spectrum) {  // a dirty record whose spectrum is resident is as good as a clean one (spectrum_is_resident)
+            if (!spectrum_is_resident(c, i, tmp[i])) return 0;
+            tmp[i].should_generate_spectrum = 0;
+        }
+    }
+    const int depth = tick_groups_usable(c, tmp, count);
+    if (depth == 0 || (depth > 0) != (ra.kind == 1)) return 0;
+    for (int i = 0; i < count; ++i) {  // launch slot i = cascade count - 1 - i
+        const ow_cascade_params &p = tmp[count - 1 - i];
+        if (p.tile_length[0] != ra.tile_x[i] || p.tile_length[1] != ra.tile_y[i]) return 0;
+    }
+    auto time_is = [&](int slot, int adds, float expect) {
+        double t = tmp[count - 1 - slot].time;
+        for (int j = 0; j < adds; ++j) t += delta;  // wave_generator.gd:103: one FP64 add per update, narrowed by the pack
+        const float ft = (float)t;
+        return std::memcmp(&ft, &expect, 4) == 0;
+    };
+    if (ra.kind == 1) {
+        if (depth != ra.D || ra.ticks < 1) return 0;
+        const int use = std::min(ra.ticks, frames);
+        for (int j = 0; j < use; ++j)
+            for (int i = 0; i < count; ++i)
+                if (!time_is(i, j + 1, ra.time[j][i])) return 0;
+    } else {
+        int sizes[OW_MAX_CASCADES];
+        const int B = pair_batches(c, count, sizes);
+        if (B < 1 || ra.batch != (c->pair_dir ? B - 1 : 0) || ra.batch >= B) return 0;
+        int first = 0;
+        for (int b = 0; b < ra.batch; ++b) first += sizes[b];
+        if (first != ra.first || sizes[ra.batch] != ra.size) return 0;
+        for (int i = first; i < first + ra.size; ++i)
+            if (!time_is(i, 1, ra.time[0][i])) return 0;
+    }
+    return depth;
+}
+
+// `ticks` >= 1 consecutive ow_update_all() ticks in groups of D = group_depth:
+//   [pass 1 of group 0] [pass 2 of group 0 + pass 1 of group 1] ... [pass 2 of the last group (+ pass 1 of the next run's first group)]
+// The scratch is a ring of 2 D ticks (tick at ring position r lives in slots (r mod 2D) * count ...); a launch reads one group and writes the next,
+// each at most D ticks.  resume: group 0's pass 1 is in the ring already (c->ra: the previous run's last launch), no first launch.
+ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, int D, bool resume, bool speculate) {
+    ow_context::RunAhead &ra = c->ra;
     c->la.armed = false;  // (the run uses the whole scratch its own way)
-    const int groups = (ticks + D - 1) / D;
-    auto group_size = [&](int g) { return std::min(D, ticks - g * D); };
-    auto slot_of_tick = [&](int t) { return (t % (2 * D)) * count; };
+    c->la.queued = 0;
+    const int ring = 2 * D;
+    const int pos = resume ? ra.pos : 0;
+    const int g0 = resume ? std::min(ra.ticks, ticks) : std::min(D, ticks);
+    ra.armed = false;  // consumed (whatever of it this run does not use is dropped)
+    auto slot_of = [&](int t) { return ((pos + t) % ring) * count; };
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.slots = count;
@@ -1279,32 +1385,61 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
     const bool pipe_fits = ow::tick_group_pipe_blocks(c->n, count) > 0 && ow::tick_group_pipe_blocks(c->n, count) <= 256;
     ga.p2_pipe = c->group_p2_form >= 0 ? c->group_p2_form : pipe_fits;
     if (ga.p2_pipe && c->group_p1_form < 0) ga.p1_compact = 1;
-    // pass 1 of group 0
+    // group 0's ticks: the records advance through them either way; their pass 1 is launched here, or has been by the previous run
     ga.d2 = 0;
-    ga.d1 = group_size(0);
-    for (int j = 0; j < ga.d1; ++j) {
+    ga.d1 = g0;
+    for (int j = 0; j < g0; ++j) {
         advance_tick(delta, params, count, ga.time1[j]);
-        ga.tbase1[j] = slot_of_tick(j);
+        ga.tbase1[j] = slot_of(j);
     }
     ow::FrameArgs args = run_frame_args(params, count);
-    if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
-    for (int g = 0; g < groups; ++g) {
-        ga.d2 = group_size(g);
-        for (int j = 0; j < ga.d2; ++j) ga.tbase2[j] = slot_of_tick(g * D + j);
-        ga.d1 = g + 1 < groups ? group_size(g + 1) : 0;
-        for (int j = 0; j < ga.d1; ++j) {
+    if (resume) {
+        c->la.hits += (uint64_t)g0;
+    } else if (ow_status st = launch_merged(c, args, ga); st != OW_OK) {
+        return st;
+    }
+    for (int done = 0, size = g0; done < ticks;) {
+        ga.d2 = size;
+        for (int j = 0; j < size; ++j) ga.tbase2[j] = slot_of(done + j);
+        const int next = std::min(D, ticks - done - size);
+        bool arming = false;
+        ga.d1 = next;
+        for (int j = 0; j < next; ++j) {
             advance_tick(delta, params, count, ga.time1[j]);
-            ga.tbase1[j] = slot_of_tick((g + 1) * D + j);
+            ga.tbase1[j] = slot_of(done + size + j);
+        }
+        if (next == 0 && speculate) {  // the run's last launch: pass 1 of the first group of a run like this one, should it follow
+            ow_cascade_params ahead[OW_MAX_CASCADES];
+            for (int i = 0; i < count; ++i) ahead[i] = params[i];
+            const int S = std::min(D, ticks);
+            ga.d1 = S;
+            for (int j = 0; j < S; ++j) {
+                advance_tick(delta, ahead, count, ga.time1[j]);
+                ga.tbase1[j] = slot_of(ticks + j);
+                for (int i = 0; i < count; ++i) ra.time[j][i] = ga.time1[j][i];
+            }
+            for (int i = 0; i < count; ++i) {
+                ra.tile_x[i] = params[count - 1 - i].tile_length[0];
+                ra.tile_y[i] = params[count - 1 - i].tile_length[1];
+            }
+            ra.kind = 1, ra.count = count, ra.D = D, ra.ticks = S, ra.pos = (pos + ticks) % ring;
+            arming = true;
         }
         if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
+        if (arming) {
+            ra.armed = true;
+            ++c->la.speculated;
+        }
+        done += size;
+        size = next;
     }
     finish_merged_run(c, args, params, count, count, 5, D);
     return OW_OK;
 }
 
-// `ticks` >= 2 consecutive ow_update_all() ticks of the compact family as tick pairs: the run is a stream of batches (B per tick, launch
-// slots in the order ow_update_all takes them), launch i = [pass 2 of batch i - 1 + pass 1 of batch i]; batch i's intermediate lives in
-// scratch slots (i mod 2) * pair_slots ...
+// `ticks` >= 1 consecutive ow_update_all() ticks of the compact family as tick pairs: the run is a stream of batches (B per tick, launch
+// slots in the order ow_update_all takes them), launch i = [pass 2 of batch i + pass 1 of batch i + 1]; the intermediates alternate between the two
+// halves of the scratch (pair_slots each).
 // ORDER OF THE STREAM.  Cascades are independent and a batch's ticks only have to follow each other, so any interleaving of the batches'
 // tick sequences leaves the same bits behind.  A tick of several batches goes CASCADE-major in blocks of kPairTickBlock ticks: batch 0 through
 // 64 ticks, then batch 1 through the same 64, ... -- every launch pairs pass 2 of a batch with pass 1 of THE SAME batch one tick later, so
@@ -1316,7 +1451,7 @@ ow_status run_tick_groups(ow_context *c, double delta, ow_cascade_params *params
 // Measured (us per tick, one launch per pass | pairs tick-major | cascade-major x 64; profiles/r04_2048_pairs.txt, r04_pairs_order_1024.txt):
 // 2048^2 x 2 123.8 | 140.2 | 117.2;  x 4 260.7 | 275.2 | 235.5;  x 8 554.9 | 520.5 | 471.9;  1024^2 x 5 76.4 | 75.8 | 68.5;  1024^2 x 8 110.1 |
 // 108.4 (half-size batches) | 104.9 (full-size) -- bit-identical maps.  Only the final state of a run is defined for a caller (ow_run =
-// `frames` ow_update_all calls back to back), and it is the same.
+// `frames` ow_update_all calls back to back), and it is the same.  The blocks alternate in direction (0 .. B-1, then B-1 .. 0: round 6, see above).
 constexpr int kPairTickBlock = 64;
 void advance_slots(double delta, ow_cascade_params *params, int count, int first_slot, int nslots, float *time_out) {  // launch slot i = cascade count-1-i
     for (int i = first_slot; i < first_slot + nslots; ++i) {
@@ -1325,22 +1460,29 @@ void advance_slots(double delta, ow_cascade_params *params, int count, int first
         time_out[i] = (float)p.time;
     }
 }
-ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks) {
+ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params, int count, int ticks, bool resume, bool speculate) {
+    ow_context::RunAhead &ra = c->ra;
     c->la.armed = false;  // (the run uses the whole scratch its own way)
+    c->la.queued = 0;
     int sizes[OW_MAX_CASCADES], first[OW_MAX_CASCADES];
     const int B = pair_batches(c, count, sizes);
     for (int b = 0, at = 0; b < B; ++b) {
         first[b] = at;
         at += sizes[b];
     }
-    // the stream: which batch each launch's pass 1 belongs to
+    // the stream: which batch each launch's pass 2 belongs to
     const int block = c->pair_tick_block > 0 ? c->pair_tick_block : kPairTickBlock;
     const int D = B > 1 ? std::min(ticks, block) : 1;
+    int dir = c->pair_dir & 1;
     std::vector<uint8_t> order;
     order.reserve((size_t)ticks * B);
-    for (int t0 = 0; t0 < ticks; t0 += D)
-        for (int b = 0; b < B; ++b)
-            for (int j = 0; j < std::min(D, ticks - t0); ++j) order.push_back((uint8_t)b);
+    for (int t0 = 0; t0 < ticks; t0 += D) {
+        for (int bi = 0; bi < B; ++bi)
+            for (int j = 0; j < std::min(D, ticks - t0); ++j) order.push_back((uint8_t)(dir ? B - 1 - bi : bi));
+        dir ^= 1;
+    }
+    const int q0 = resume ? ra.parity : 0;  // half of the scratch that holds pass 1 of the stream's first entry
+    ra.armed = false;
     ow::TickGroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.pair_compact = 1;
@@ -1353,34 +1495,59 @@ ow_status run_tick_pairs(ow_context *c, double delta, ow_cascade_params *params,
     }
     ow::FrameArgs args = run_frame_args(params, count);
     const int total = (int)order.size();
-    for (int i = 0; i <= total; ++i) {
-        ga.slots2 = ga.slots1 = 0;
-        if (i >= 1) {
-            const int b = order[i - 1];
-            ga.first2 = first[b];
-            ga.slots2 = sizes[b];
-            ga.tbase2[0] = ((i - 1) & 1) * c->pair_slots;
+    {   // pass 1 of the stream's first entry: launched alone here, or by the previous run's last launch
+        const int b = order[0];
+        advance_slots(delta, params, count, first[b], sizes[b], ga.time1[0]);
+        if (resume) {
+            ++c->la.hits;
+        } else {
+            ga.slots2 = 0, ga.d2 = 0;
+            ga.first1 = first[b], ga.slots1 = sizes[b], ga.d1 = 1;
+            ga.tbase1[0] = (q0 & 1) * c->pair_slots;
+            if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
         }
-        if (i < total) {
-            const int b = order[i];
-            advance_slots(delta, params, count, first[b], sizes[b], ga.time1[0]);  // this batch's next tick
+    }
+    for (int i = 0; i < total; ++i) {
+        const int b = order[i];
+        ga.first2 = first[b];
+        ga.slots2 = sizes[b];
+        ga.tbase2[0] = ((q0 + i) & 1) * c->pair_slots;
+        ga.slots1 = 0;
+        bool arming = false;
+        if (i + 1 < total) {
+            const int nb = order[i + 1];
+            advance_slots(delta, params, count, first[nb], sizes[nb], ga.time1[0]);  // that batch's next tick
+            ga.first1 = first[nb];
+            ga.slots1 = sizes[nb];
+        } else if (speculate) {  // the run's last launch: the next tick of the batch the run ends on -- what a run like this one would start with (dir has turned)
+            for (int s = first[b]; s < first[b] + sizes[b]; ++s) {
+                const ow_cascade_params &p = params[count - 1 - s];
+                ga.time1[0][s] = ra.time[0][s] = (float)(p.time + delta);
+            }
+            for (int s = 0; s < count; ++s) {
+                ra.tile_x[s] = params[count - 1 - s].tile_length[0];
+                ra.tile_y[s] = params[count - 1 - s].tile_length[1];
+            }
             ga.first1 = first[b];
             ga.slots1 = sizes[b];
-            ga.tbase1[0] = (i & 1) * c->pair_slots;
+            ra.kind = 2, ra.count = count, ra.batch = b, ra.first = first[b], ra.size = sizes[b], ra.parity = (q0 + i + 1) & 1;
+            arming = true;
         }
-        ga.d2 = ga.slots2 > 0;
+        ga.tbase1[0] = ((q0 + i + 1) & 1) * c->pair_slots;
+        ga.d2 = 1;
         ga.d1 = ga.slots1 > 0;
         if (ow_status st = launch_merged(c, args, ga); st != OW_OK) return st;
+        if (arming) {
+            ra.armed = true;
+            ++c->la.speculated;
+        }
     }
-    finish_merged_run(c, args, params, count, sizes[B - 1], 6, 1);
+    c->pair_dir = dir;
+    finish_merged_run(c, args, params, count, sizes[order[total - 1]], 6, 1);
     return OW_OK;
 }
 
-}  // namespace
-
-ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
-    if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
-    if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+ow_status run_impl(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
     // (measurements only: an irregular cadence for the call-by-call forms below)
     auto delta_of = [&](int tick) { return c->run_delta_period > 0 && ((tick / c->run_delta_period) & 1) ? delta * 1.25 : delta; };
     if (c->run_as_reference) {  // measurement: the reference's own schedule, call by call
@@ -1414,16 +1581,33 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         }
         return OW_OK;
     }
-    // the first tick always takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
+    const bool may_merge = !c->run_as_calls && !c->no_merge && std::isfinite(delta) && count >= 1 && count <= c->cascades;
+    // a run that follows a run (same delta, same cascades, nothing in between) lets its last launch work ahead for the next one
+    const bool speculate = may_merge && c->ra.run_streak >= 1 && c->timing == 0 && !c->inject_fault;
+    // ... and the next one starts in the middle of the stream: no ordinary first tick, no launch of pass 1 alone
+    if (may_merge && frames >= 1 && c->ra.armed) {
+        const int depth = run_resume_usable(c, delta, params, count, frames);
+        if (depth != 0) {
+            OW_HIP(hipSetDevice(c->device));
+            for (int i = 0; i < count; ++i)
+                if (params[i].should_generate_spectrum) {  // (resident: checked)
+                    params[i].should_generate_spectrum = 0;
+                    ++c->spectra_skipped;
+                }
+            note_cadence(c, delta);  // (what the first tick's ow_update_all would have noted)
+            return depth > 0 ? run_tick_groups(c, delta, params, count, frames, depth, true, speculate) : run_tick_pairs(c, delta, params, count, frames, true, speculate);
+        }
+    }
+    // the first tick takes the ordinary path (flush of leftovers, spectrum generation, validation of the records) ...
     if (frames >= 1) {
-        c->la.hold = frames >= 3 && !c->run_as_calls && !c->no_merge;  // (the run's own merged launches take over from tick 2 on)
+        c->la.hold = frames >= 3 && may_merge;  // (the run's own merged launches take over from tick 2 on)
         ow_status st = ow_update_all(c, delta, params, count);
         c->la.hold = false;
         if (st != OW_OK) return st;
         f = 1;
     }
     // ... the rest of a small batch goes out as tick groups (results identical: same lane code, same order per texel)
-    int depth = frames - f >= 2 && std::isfinite(delta) && !c->run_as_calls ? tick_groups_usable(c, params, count) : 0;
+    int depth = frames - f >= 2 && may_merge ? tick_groups_usable(c, params, count) : 0;
     if (depth != 0) {
         OW_HIP(hipSetDevice(c->device));
         // the merged launches keep several ticks of intermediate in flight; if that scratch cannot be had the run is not lost: it goes
@@ -1431,7 +1615,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         if (ensure_scratch(c, depth > 0 ? 2 * depth * count : 2 * c->pair_slots) != OW_OK) depth = 0;
     }
     if (depth != 0) {
-        ow_status st = depth > 0 ? run_tick_groups(c, delta, params, count, frames - f, depth) : run_tick_pairs(c, delta, params, count, frames - f);
+        ow_status st = depth > 0 ? run_tick_groups(c, delta, params, count, frames - f, depth, false, speculate) : run_tick_pairs(c, delta, params, count, frames - f, false, speculate);
         if (st != OW_OK) return st;
         f = frames;
     }
@@ -1440,6 +1624,25 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
         if (st != OW_OK) return st;
     }
     return OW_OK;
+}
+
+}  // namespace
+
+ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t count, int32_t frames) {
+    if (frames < 0) return fail(OW_ERR_INVALID, "frames must be >= 0");
+    if (!c || !params) return fail(OW_ERR_INVALID, "null argument");
+    // does this run follow a run like itself, with nothing in between?  (update_impl lowers last_was_run when it is called from outside a run)
+    ow_context::RunAhead &ra = c->ra;
+    const bool follows = ra.last_was_run && ra.last_count == count && std::memcmp(&ra.last_delta, &delta, sizeof(double)) == 0;
+    ra.run_streak = follows ? std::min(ra.run_streak + 1, 1 << 20) : 0;
+    c->inside_run = true;
+    const ow_status st = run_impl(c, delta, params, count, frames);
+    c->inside_run = false;
+    ra.last_was_run = st == OW_OK && frames >= 1;
+    ra.last_count = count;
+    ra.last_delta = delta;
+    if (st != OW_OK) ra.armed = false;
+    return st;
 }
 
 int32_t ow_last_kernel_family(const ow_context *c) { return c ? c->last_family : 0; }
@@ -1785,6 +1988,7 @@ ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float
     if (reps < 1 || c->last_count < 1) return fail(OW_ERR_STATE, "nothing has been launched yet (or reps < 1)");
     OW_HIP(hipSetDevice(c->device));
     c->la.armed = false;  // (the probe launches write the scratch intermediate from slot 0 on)
+    c->ra.armed = false;
     hipEvent_t e[3] = {};
     float a = 0, b = 0;
     auto run = [&]() -> ow_status {

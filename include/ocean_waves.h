@@ -97,7 +97,7 @@ typedef struct ow_config {
  * intermediate instead of the reference's four; ow_get_intermediate is not available for batches that used them.
  * Together with OW_FLAG_KERNELS_LAYER_PARALLEL: the layer-parallel kernels on the compact intermediate (map_size >= 256). */
 #define OW_FLAG_KERNELS_COMPACT 8u
-/* ow_run merges launches across ticks where that pays (the first tick of a run always takes the ordinary path):
+/* ow_run merges launches across ticks where that pays (the first tick of a run takes the ordinary path unless the run continues a previous one, see ow_run):
  *  - TICK GROUPS, small batches (the layer-parallel compact family): one launch does pass 2 of up to four (256^2 x <= 4: eight)
  *    consecutive ticks (a block walks through the ticks of its rows, foam in registers) together with pass 1 of the next ones
  *    (independent of everything earlier) -- K / 4 + 1 launches for K ticks, and a chip that one small tick cannot fill is filled
@@ -127,6 +127,11 @@ typedef struct ow_config {
 /* Tests / measurements: every raised should_generate_spectrum launches the spectrum kernel, as the reference's _update does
  * (wave_generator.gd:68-72), even when the record packs to the very constants the resident spectrum was generated from (ow_spectrum_stats). */
 #define OW_FLAG_ALWAYS_REGENERATE_SPECTRUM 0x1000u
+/* ow_create allocates the scratch intermediate of ONE batch only; what the look-ahead of ow_update_all / ow_process keeps in flight (the pair
+ * kernel two batches, the group kernel a ring of five groups: 160 MiB at 1024^2 x 1, ~240 MiB at 512^2 x 8) is then allocated by the first call
+ * that speculates (one hipMalloc + stream synchronisation inside that call, none afterwards).  For contexts that are only driven through ow_run's
+ * tick groups, or many shards on one device; the default keeps every per-frame call free of allocations. */
+#define OW_FLAG_LAZY_SCRATCH 0x2000u
 
 typedef struct ow_context ow_context;
 
@@ -209,7 +214,18 @@ ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *sp
 ow_status ow_spectrum_stats(const ow_context *ctx, uint64_t *generated, uint64_t *skipped);
 
 /* `frames` consecutive ow_update_all() ticks with the same delta, enqueued back to back (the reference's
- * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times. */
+ * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times: only the state a run leaves
+ * behind is defined (inside it the runtime may order independent cascades' ticks as it likes, see OW_FLAG_NO_TICK_GROUPS).
+ * WORK LEFT IN THE QUEUE.  Runs that follow each other are one seamless stream of full launches, which means that the last launch of a run may
+ * carry pass 1 of the tick(s) a NEXT run would start with, still in flight when ow_run returns (ow_sync / a readback wait for it like for anything
+ * else; a next call that does not match discards it; the maps and every state a caller can observe are unaffected):
+ *  - single-batch ticks of the compact family (1024^2 x 2 .. 4, 512^2 x 7 .. 8, 2048^2 x 1): the run's last tick speculates one more tick by
+ *    ow_update_all's cadence rule (after a run of equal deltas: always);
+ *  - tick groups and multi-batch tick pairs (256^2, 512^2 x <= 6, 1024^2 x 1; 1024^2 x 5 .. 8, 2048^2 x 2 .. 8): only a run that itself FOLLOWED a run
+ *    with the same delta and cascade count, nothing in between, works ahead for the next one -- the first group of ticks, or the next tick of the
+ *    batch the run ended on -- so a one-shot caller (one ow_run, then a readback) leaves nothing behind.  The next run checks it like a look-ahead
+ *    hit (count, every FP32 time and tile length bit for bit, nothing armed, no spectrum to generate, nothing else has used the scratch) and then
+ *    starts in the middle of the stream: no ordinary first tick, no half-filled launches at the ends of a run (ow_lookahead_stats counts both). */
 ow_status ow_run(ow_context *ctx, double delta, ow_cascade_params *params, int32_t count, int32_t frames);
 
 /* Number of armed, unprocessed cascades (pass_num_cascades_remaining, wave_generator.gd:15). */

@@ -75,6 +75,12 @@ def schedule(n, count, seed, ops=60):
                     frames = rng.randint(60, 70)
                 d = delta
                 both(f"run({frames})", lambda g, p: g.run(d, p, frames))
+                if rng.random() < 0.5:   # runs that follow runs: the last launch of one works ahead for the next, which resumes in the middle of the stream
+                    for _ in range(rng.randint(1, 3)):
+                        more = rng.choice((frames, frames, rng.randint(1, 9), rng.randint(10, 30)))
+                        both(f"run({more}) after a run", lambda g, p: g.run(d, p, more))
+                        if rng.random() < 0.2:   # reading the maps in between disturbs nothing
+                            compare(a, b, count, f"between runs at step {step}")
             elif r < 0.84:
                 i, t = rng.randrange(count), (rng.uniform(8.0, 300.0), rng.uniform(8.0, 300.0))
                 def edit(g, p):

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 6, generic visit: PARTS="new suite bench overhead kbench" OUT=name bash scripts/r06_visit.sh   (logs under gpurun_out/$OUT)
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=${OUT:-r06_v1}; O=gpurun_out/$OUT; mkdir -p $O; export TMPDIR=/tmp
+PARTS=${PARTS:-new suite bench overhead kbench}
+want() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+if want new; then   # what this round changed, first and without -x: every failure is worth seeing
+timeout 1500 python -m pytest tests/test_run_after_run.py tests/test_spectrum_resident.py tests/test_parity_margins.py tests/test_tick_groups.py \
+  "tests/test_group.py::test_link_info_says_how_each_shard_reaches_the_root" "tests/test_gpu_parity.py::test_baseline_configs_through_ow_run_match_the_oracle" \
+  "tests/test_lookahead.py" -m gpu -q --timeout 900 > $O/pytest_new.log 2>&1; echo "pytest rc=$?" >> $O/pytest_new.log; tail -30 $O/pytest_new.log
+fi
+if want suite; then
+timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -15 $O/pytest.log
+fi
+if want bench; then
+( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; tail -c 2500 $O/bench_driver_cmd.json; tail -5 $O/bench_driver_cmd.err
+fi
+if want overhead; then
+timeout 900 python scripts/run_overhead.py 1024:8 2048:4 256:4 1024:4 > $O/run_overhead.txt 2>&1; cat $O/run_overhead.txt
+fi
+if want kbench; then
+for b in exp c16 c64 c512; do
+  echo "== tools/kbench_2048pair_$b" >> $O/kbench.txt
+  timeout 300 tools/kbench_2048pair_$b 4 40 2>&1 | grep -v "clocks\|waves\|issued\|table\|modulated\|input\|transformed\|staged\|acknowledged" >> $O/kbench.txt
+done
+cat $O/kbench.txt
+fi
+if want fuzz; then
+timeout 1500 python scripts/fuzz_schedule.py ${FUZZ_N:-12} ${FUZZ_SEED:-601} > $O/fuzz_schedule.txt 2>&1; tail -14 $O/fuzz_schedule.txt
+fi
