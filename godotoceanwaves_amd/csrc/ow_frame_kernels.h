@@ -55,7 +55,9 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef OW_ROWSYNC_FREE_POLLS
 #define OW_ROWSYNC_FREE_POLLS 0
 #endif
-template <int N>
+// BLOCK (N = 2048 only; A/B builds, OW_P2_PAIR_BLOCK_BARRIER): the rendezvous is the workgroup's LDS barrier instead -- no spin, no bounded wait, no
+// status report (a barrier cannot give up), every wave of the block in step at every exchange; only where all waves of the block run the same sequence
+template <int N, bool BLOCK = false>
 struct RowSync {
     typedef __attribute__((address_space(3))) int lds_int;
     volatile lds_int *mine = nullptr, *partner = nullptr;
@@ -77,7 +79,9 @@ struct RowSync {
         }
     }
     __device__ __forceinline__ void sync() {
-        if constexpr (plan_row_spans_waves(N)) {
+        if constexpr (BLOCK && plan_row_spans_waves(N)) {
+            lds_barrier();
+        } else if constexpr (plan_row_spans_waves(N)) {
             ++epoch;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // s_waitcnt lgkmcnt(0): my LDS reads/writes are done
             if (!mute) *mine = epoch;
@@ -232,8 +236,8 @@ struct TablePrefetch {
 // other waves may still be draining the previous layer's staged rows out of them)
 // (gate(): called right before the first write into the row regions)
 // (TWH: tw is the half table of ow_device.h "HALF TABLE")
-template <int N, bool TWH = false, class Gate>
-__device__ __forceinline__ void row_ifft_gated(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RowSync<N> &rs, Gate gate) {
+template <int N, bool TWH = false, class RS, class Gate>
+__device__ __forceinline__ void row_ifft_gated(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RS &rs, Gate gate) {
     fft_stage_compute<N, 0, TWH>(d, t, tw);
     gate();
     fft_stage_write<N, 0>(d, t, lds_row);
@@ -253,8 +257,8 @@ __device__ __forceinline__ void row_ifft_gated(cplx *d, int t, cplx *lds_row, co
         fft_stage_compute<N, 2>(d, t, tw);
     }
 }
-template <int N, bool BLOCK_GATE = false, bool TWH = false>
-__device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RowSync<N> &rs) {
+template <int N, bool BLOCK_GATE = false, bool TWH = false, class RS>
+__device__ __forceinline__ void row_ifft(cplx *d, int t, cplx *lds_row, const cplx *__restrict__ tw, RS &rs) {
     row_ifft_gated<N, TWH>(d, t, lds_row, tw, rs, [] {
         if constexpr (BLOCK_GATE) lds_barrier();
     });
@@ -668,9 +672,9 @@ constexpr bool p2c_half_table(int N) { return plan_row_spans_waves(N); }
 constexpr int p2c_table_total(int N) { return p2c_half_table(N) ? plan_twh_total(N) : plan_tw_total(N); }
 template <int N>
 __device__ __forceinline__ const cplx *p2c_table(const DeviceBuffers &buf) { return p2c_half_table(N) ? buf.tw_half : buf.tw; }
-template <int N, bool F32, int AUX_T, int AUX_O, class Issued>
+template <int N, bool F32, int AUX_T, int AUX_O, class RS, class Issued>
 __device__ __forceinline__ void pass2c_item(const DeviceBuffers &buf, const CascadeFrame &cf, int tslot, int row0, int tau, cplx *tw_lds, cplx *rows_lds,
-                                            RowSync<N> &rs, Issued issued, uint32_t (&foam_pk)[kP / 2], int foam_io = 3) {
+                                            RS &rs, Issued issued, uint32_t (&foam_pk)[kP / 2], int foam_io = 3) {
     constexpr int Tn = plan_T(N), P = kP;
     constexpr bool TWH = p2c_half_table(N);
     const int rw = (Tn >= 64) ? __builtin_amdgcn_readfirstlane(tau / Tn) : tau / Tn, t = tau % Tn;
@@ -1057,7 +1061,10 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
         cplx *rows_lds = lds + PG::kP2Tw;
         const int tau = threadIdx.x;
         int *sync_flags = reinterpret_cast<int *>(lds + PG::kP2Tw + PG::kCols * plan_region_cplx(N));
-        RowSync<N> rs;
+#ifndef OW_P2_PAIR_BLOCK_BARRIER
+#define OW_P2_PAIR_BLOCK_BARRIER 0
+#endif
+        RowSync<N, OW_P2_PAIR_BLOCK_BARRIER != 0> rs;
         rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
         rs.watch(buf.status, g.fault);
         init_row_sync<N>(sync_flags, PG::kCols);

@@ -796,53 +796,83 @@ bool lookahead_process(ow_context *c, int idx, ow_status *out) {
 // for the next one to flush was recomputed from scratch although its pass 1 had long been done (the flush now consumes the queue: flush_from_queue).
 // Round 5, the scene's cadence at 1024^2 x 4 (roofline.scene_schedule): 144 Hz frames 110 -> 83 us per update, 60 Hz 137-142 -> 81, the heaviest
 // frame 91 -> 61 us (144 Hz).
-void lookahead_prearm(ow_context *c) {
+// how many of the cascades the ow_process calls will take (records[count - 1], [count - 2], ..) one launch can compute pass 1 for, 0 = none
+int prearm_depth(const ow_context *c, const ow_cascade_params *records, int count) {
+    constexpr int kRing = ow_context::Lookahead::kMaxAhead;
+    if (lookahead_mode(c, 1) != 2) return 0;  // the group kernel's form only (a cascade of the layer-parallel compact family: <= 1 Mi texels)
+    const int idx = count - 1;
+    int depth = std::min(idx + 1, std::min(kRing, c->ahead_depth));
+    for (int k = 0; k < depth; ++k) {
+        const ow_cascade_params &p = records[idx - k];
+        if (p.should_generate_spectrum || validate_record(p, idx - k) != OW_OK) depth = k;
+    }
+    return depth;
+}
+// does the head of the queue hold pass 1 of `cascade` as record p asks for it (one cascade per entry: the reference's schedule)?
+bool queue_head_serves(const ow_context *c, int cascade, const ow_cascade_params &p) {
+    const ow_context::Lookahead &la = c->la;
+    if (!la.armed || la.queued < 1 || la.count != 1 || la.mode != 2) return false;
+    const float t = (float)p.time;
+    const int h = la.head;
+    return la.cascade[h][0] == cascade && std::memcmp(&t, &la.time[h][0], 4) == 0 && p.tile_length[0] == la.tile_x[h][0] && p.tile_length[1] == la.tile_y[h][0];
+}
+// THE LEFTOVER RIDES WITH THE NEXT UPDATE'S PASS 1 (round 6).  On the scene's own cadence (144 Hz frames, an update every third frame, one ow_process per
+// frame) every update finds ONE cascade of the previous arm unprocessed, its pass 1 waiting at the head of the queue, and used to launch its pass 2 alone
+// (flush_from_queue: a quarter-filled launch) right in front of the pre-arm launch.  Both are inside this ow_update, independent of each other, and the
+// group kernel takes exactly this shape -- pass 2 of one cascade (the layer-parallel family's block, what a batch of one takes anyway: bit-identical to
+// the flush it replaces) beside pass 1 of up to four others, as every refilling ow_process launches it: `flush` = that leftover record, or nullptr.
+// records: the armed records of this update.  Returns 1 = launched, 0 = nothing to launch (the ow_process calls take what they find), -1 = the launch failed.
+int prearm_launch(ow_context *c, const ow_cascade_params *records, int count, const ow_cascade_params *flush) {
     ow_context::Lookahead &la = c->la;
     constexpr int kRing = ow_context::Lookahead::kMaxAhead;
-    if (lookahead_mode(c, 1) != 2) return;  // the group kernel's form only (a cascade of the layer-parallel compact family: <= 1 Mi texels)
-    const int idx = c->pass_num_cascades_remaining - 1;
-    if (la.armed && la.queued > 0) {
+    const int idx = count - 1;
+    if (!flush && la.armed && la.queued > 0) {
         // Work computed ahead is waiting already.  If its head is what the first ow_process of this update will ask for (a regular cadence: the previous
         // update's last ow_process guessed right), leave it.  If it cannot hit -- pair-kernel entries left by ow_update_all, a guess made with another
         // delta -- that call would miss, launch a lone pass 1 and refill: the round-4 path.  Drop the stale queue and pre-arm instead.
-        const ow_cascade_params &p = c->pass_parameters[idx];
-        const float t = (float)p.time;
-        const int h = la.head;
-        if (la.count == 1 && la.mode == 2 && la.cascade[h][0] == idx && std::memcmp(&t, &la.time[h][0], 4) == 0 && p.tile_length[0] == la.tile_x[h][0] &&
-            p.tile_length[1] == la.tile_y[h][0])
-            return;
+        if (lookahead_mode(c, 1) == 2 && queue_head_serves(c, idx, records[idx])) return 0;
         la.armed = false;
         la.queued = 0;
     }
-    int depth = std::min(idx + 1, std::min(kRing, c->ahead_depth));
-    for (int k = 0; k < depth; ++k) {
-        const ow_cascade_params &p = c->pass_parameters[idx - k];
-        if (p.should_generate_spectrum || validate_record(p, idx - k) != OW_OK) depth = k;
-    }
-    if (depth < 1) return;
+    const int depth = prearm_depth(c, records, count);
+    if (depth < 1) return 0;
     const int groups = kRing + 1, stride = 1;
-    if (ensure_scratch(c, groups * stride) != OW_OK) return;
+    if (ensure_scratch(c, groups * stride) != OW_OK) return 0;  // (a pre-arm that would have to grow the scratch and cannot is simply not made; never with `flush`: its entry lives there)
     c->ra.armed = false;
-    const int cur = 0;  // (nothing is queued and everything launched so far precedes this launch in stream order: any group will do -- the entries then
-                        //  sit in groups 1 .. depth, consecutive scratch slots without a wrap of the ring, which is what flush_from_queue needs)
+    // the group that holds the launch's own pass-2 intermediate: the leftover's queue entry, or none (nothing is queued and everything launched so far
+    // precedes this launch in stream order: the entries then sit in groups 1 .. depth, consecutive slots without a wrap, which is what flush_from_queue needs)
+    const int cur = flush ? la.group[la.head] : 0;
+    const int first1 = flush ? 1 : 0;
     ow::FrameArgs args;
     ow::TickGroupArgs ga;
     std::memset(&args, 0, sizeof(args));
     std::memset(&ga, 0, sizeof(ga));
+    if (flush) {  // launch slot 0: pass 2 of cascade 0 of the previous arm, exactly as flush_from_queue would have launched it
+        c->maps_faulted &= ~1u;
+        c->enqueued_since_sync |= 1u;
+        record_frame_constants(c, 0, *flush);
+        args.c[0] = frame_of(*flush, 0);
+        c->last_args = args;
+        c->last_count = 1;
+        c->last_family = ow::kernel_family(c->n, 1, c->kernel_mode);
+        for (int &sl : c->slot_of) sl = -1;
+        ga.d2 = 1;
+        ga.tbase2[0] = cur * stride;
+        ++la.hits;
+    }
     la.head = 0;
     for (int k = 0; k < depth; ++k) {
-        const ow_cascade_params &p = c->pass_parameters[idx - k];
+        const ow_cascade_params &p = records[idx - k];
         la.group[k] = (cur + 1 + k) % groups;
         ga.tbase1[k] = la.group[k] * stride;
-        args.c[k] = frame_of(p, idx - k);            // pass-1 "tick" k = launch slot k (first1 = 0, step1 = 1): tile lengths and layer from it, the time from time1
-        la.time[k][0] = ga.time1[k][0] = (float)p.time;
+        args.c[first1 + k] = frame_of(p, idx - k);   // pass-1 "tick" k = launch slot first1 + k (step1 = 1): tile lengths and layer from it, the time from time1
+        la.time[k][0] = ga.time1[k][first1] = (float)p.time;
         la.cascade[k][0] = idx - k;
         la.tile_x[k][0] = p.tile_length[0];
         la.tile_y[k][0] = p.tile_length[1];
     }
-    ga.d2 = 0;
     ga.d1 = depth;
-    ga.first1 = 0;
+    ga.first1 = first1;
     ga.step1 = 1;
     ga.slots = 1;
     ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
@@ -850,7 +880,7 @@ void lookahead_prearm(ow_context *c) {
         (void)hipGetLastError();
         la.armed = false;
         la.queued = 0;
-        return;  // (nothing is lost: the ow_process calls take the ordinary path -- and report the device's state themselves)
+        return -1;  // (without `flush` nothing is lost: the ow_process calls take the ordinary path -- and report the device's state themselves)
     }
     la.queued = depth;
     la.armed = true;
@@ -858,6 +888,7 @@ void lookahead_prearm(ow_context *c) {
     la.mode = 2;
     la.cur_group = cur;
     la.speculated += 1;
+    return 1;
 }
 
 // The flush of ow_update (wave_generator.gd:94-98: the cascades 0 .. left - 1 the previous arm never got to) from the queue: if pass 1 of EVERY
@@ -1130,6 +1161,24 @@ ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, in
     // the new records are checked BEFORE anything changes: a refused call has advanced no time, consumed no dirty flag, armed nothing
     if (ow_status st = ow::validate_records(params, count, delta); st != OW_OK) return st;
     OW_HIP(hipSetDevice(c->device));
+    // what this update arms, computed aside first (:101-106; GDScript floats are FP64): nothing of `params` or of the context changes before the
+    // leftovers' flush has been launched -- a call that fails there can simply be repeated
+    ow_cascade_params next[OW_MAX_CASCADES], armed[OW_MAX_CASCADES];
+    for (int i = 0; i < count; ++i) {
+        ow_cascade_params &p = next[i];
+        p = params[i];
+        p.time += delta;
+        p.foam_grow_rate = delta * p.foam_amount * 7.5;
+        const double d = 10.0 - p.foam_amount;
+        p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
+        armed[i] = p;                     // :108 -- a copy: `params` is not touched after this call returns
+        p.should_generate_spectrum = 0;   // consumed: the armed copy carries it until the cascade is processed (:72)
+    }
+    // ... unless the spectrum it asks for is the one that is there (spectrum_is_resident) -- asked AFTER the flush, which may itself regenerate a layer
+    auto settle_armed = [&]() {
+        for (int i = 0; i < count; ++i) settle_dirty_flag(c, i, armed[i]);
+    };
+    bool prearmed = false;
     if (c->pass_num_cascades_remaining != 0) {  // :94-98: leftovers of the previous arm, with the previous records
         int idx[OW_MAX_CASCADES];
         const int left = c->pass_num_cascades_remaining;
@@ -1139,25 +1188,29 @@ ow_status update_impl(ow_context *c, double delta, ow_cascade_params *params, in
         // nothing of `params` has been touched yet, so the call can simply be repeated.)
         c->pass_num_cascades_remaining = 0;
         ow_status st = OW_OK;
-        // (their pass 1 may be waiting in the queue, computed ahead for the ow_process calls that never came: then the flush is one pass-2 launch)
-        if (!flush_from_queue(c, left, &st)) st = enqueue(c, c->pass_parameters, idx, left);
+        const ow_cascade_params leftover = c->pass_parameters[0];
+        // ONE leftover whose pass 1 waits alone at the head of the queue, and an update whose cascades can be pre-armed: its pass 2 rides in the pre-arm launch
+        // (the leftover has no spectrum to regenerate, so the resident spectra the new records are settled against are already the ones they will meet)
+        if (process_calls_follow && left == 1 && c->la.queued == 1 && !leftover.should_generate_spectrum && validate_record(leftover, 0) == OW_OK &&
+            lookahead_mode(c, 1) == 2 && batch_size(c, 1) == 1 && queue_head_serves(c, 0, leftover) && (settle_armed(), prearm_depth(c, armed, count) >= 1)) {
+            const int r = prearm_launch(c, armed, count, &leftover);
+            if (r < 0) return fail(OW_ERR_HIP, "the launch that flushes the previous update's leftover failed");
+            prearmed = r > 0;
+        }
+        // (otherwise their pass 1 may still be waiting in the queue, computed ahead for the ow_process calls that never came: then the flush is one pass-2 launch)
+        if (!prearmed && !flush_from_queue(c, left, &st)) st = enqueue(c, c->pass_parameters, idx, left);
         if (st != OW_OK) return st;
     }
+    settle_armed();
     note_cadence(c, delta);
     if (!c->inside_run) c->ra.last_was_run = false;  // (a tick issued by the caller itself: the next ow_run does not "follow a run")
-    for (int i = 0; i < count; ++i) {  // :101-106 (GDScript floats are FP64)
-        ow_cascade_params &p = params[i];
-        p.time += delta;
-        p.foam_grow_rate = delta * p.foam_amount * 7.5;
-        const double d = 10.0 - p.foam_amount;
-        p.foam_decay_rate = delta * (d > 0.5 ? d : 0.5) * 1.15;
-        c->pass_parameters[i] = p;        // :108 -- a copy: `params` is not touched after this call returns
-        p.should_generate_spectrum = 0;   // consumed: the armed copy carries it until the cascade is processed (:72)
-        settle_dirty_flag(c, i, c->pass_parameters[i]);  // ... unless the spectrum it asks for is the one that is there (spectrum_is_resident)
+    for (int i = 0; i < count; ++i) {
+        params[i] = next[i];
+        c->pass_parameters[i] = armed[i];
     }
     c->pass_count = count;
     c->pass_num_cascades_remaining = count;  // :109
-    if (process_calls_follow) lookahead_prearm(c);
+    if (process_calls_follow && !prearmed) (void)prearm_launch(c, c->pass_parameters, count, nullptr);
     return OW_OK;
 }
 }  // namespace

@@ -19,11 +19,17 @@ if want overhead; then
 timeout 900 python scripts/run_overhead.py 1024:8 2048:4 256:4 1024:4 > $O/run_overhead.txt 2>&1; cat $O/run_overhead.txt
 fi
 if want kbench; then
-for b in exp c16 c64 c512; do
-  echo "== tools/kbench_2048pair_$b" >> $O/kbench.txt
-  timeout 300 tools/kbench_2048pair_$b 4 40 2>&1 | grep -v "clocks\|waves\|issued\|table\|modulated\|input\|transformed\|staged\|acknowledged" >> $O/kbench.txt
+: > $O/kbench.txt
+for b in ${KBENCH:-exp bar}; do
+  for cs in ${KBENCH_C:-1 4}; do
+    echo "== tools/kbench_2048pair_$b $cs 40" >> $O/kbench.txt
+    timeout 300 tools/kbench_2048pair_$b $cs 40 2>&1 | grep -v "clocks\|waves\|issued\|table\|modulated\|input\|transformed\|staged\|acknowledged" >> $O/kbench.txt
+  done
 done
 cat $O/kbench.txt
+fi
+if want san; then
+OUT=$OUT bash scripts/run_sanitized.sh > $O/san_stdout.log 2>&1; tail -70 $O/san_stdout.log
 fi
 if want fuzz; then
 timeout 1500 python scripts/fuzz_schedule.py ${FUZZ_N:-12} ${FUZZ_SEED:-601} > $O/fuzz_schedule.txt 2>&1; tail -14 $O/fuzz_schedule.txt
