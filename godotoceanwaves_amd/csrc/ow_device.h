@@ -845,6 +845,9 @@ OW_DEV float modulate_kcomp(int id, int n, float tile) {
 // then for each packed layer build the row's spectrum and run the row IFFT (fft_compute.glsl, first
 // dispatch); results go to the transposed intermediate T (transpose.glsl fused into the store).
 // ------------------------------------------------------------------------------------
+#ifndef OW_OMEGA_ONE_LOAD
+#define OW_OMEGA_ONE_LOAD 1
+#endif
 template <int N>
 struct Pass1 {
     static constexpr int T = plan_T(N), P = kP;
@@ -867,7 +870,8 @@ struct Pass1 {
     // b_wrap: lane 0 of a row pairs x = 0 with x = 0 (not with x = N).
     // load_raw issues the loads (a = h0(k), b = the mirrored texel, om = omega); modulate consumes them.  Apart they let a kernel
     // put other work -- the twiddle table's way into LDS and its barrier -- between issue and first use.
-    template <int AUX = 0>
+    // (J0 .. J1 - 1: the FFT slots whose texels are asked for -- the pipelined form of the pass-1 items issues them a few at a time, pipelined_load_modulate)
+    template <int AUX = 0, int J0 = 0, int J1 = P>
     static OW_DEV void load_raw(cplx *a, cplx *b, float *om, int t, int y, GBuf h0_c, GBuf om_c) {
         const int ym = (N - y) % N;
         const int tm = (T - t) % T;                           // lane part of the mirrored column
@@ -878,18 +882,32 @@ struct Pass1 {
         const bool om_mirror = y > N / 2;
         const uint32_t o_off = (om_mirror ? (uint32_t)(ym * N + tm) : (uint32_t)(y * N + t)) * 4u;
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const int blk = rot(j);  // x = t + T*blk ;  mirrored x = (T - t) + T*(15 - blk)  [t > 0],  T*((16 - blk) % 16)  [t = 0]
             a[j] = gload8<AUX>(h0_c, a_off, (uint32_t)(T * blk) * 8u);
             const uint32_t mb = (uint32_t)(T * (15 - blk)), mb0 = (uint32_t)(T * ((16 - blk) % 16));
+            // omega, ONE load instruction whichever half the row is in where a row is wave-uniform (N >= 1024; round 6): the two forms differ in a lane
+            // offset and a wave-uniform one; written as two loads under a condition, the compiler branched around each of the sixteen, which cut the
+            // load sequence into forty basic blocks.  (Where a wave holds several rows the two predicated loads stay: a per-lane select costs more.)
+            constexpr bool one_load = OW_OMEGA_ONE_LOAD && T >= 64;
             if (blk == 0) {  // lane 0 needs block 0 here, the other lanes block 15: one lane-dependent offset
                 b[j] = gload8<AUX>(h0_c, lane0 ? b_off : b_off + mb * 8u, 0u);
-                om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off : o_off + mb * 4u, 0u) : gload4<AUX>(om_c, o_off, 0u);
+                if constexpr (one_load) om[j] = gload4<AUX>(om_c, (om_mirror && !lane0) ? o_off + mb * 4u : o_off, 0u);
+                else om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off : o_off + mb * 4u, 0u) : gload4<AUX>(om_c, o_off, 0u);
             } else {
                 b[j] = gload8<AUX>(h0_c, lane0 ? b_off + (uint32_t)T * 8u : b_off, mb * 8u);
                 (void)mb0;
-                om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off + (uint32_t)T * 4u : o_off, mb * 4u)
-                                  : gload4<AUX>(om_c, o_off, (uint32_t)(T * blk) * 4u);
+                if constexpr (one_load) {
+#if OW_DEVICE_BUILD
+                    const bool mirror_u = __builtin_amdgcn_readfirstlane((int)om_mirror) != 0;
+#else
+                    const bool mirror_u = om_mirror;
+#endif
+                    om[j] = gload4<AUX>(om_c, (om_mirror && lane0) ? o_off + (uint32_t)T * 4u : o_off, mirror_u ? mb * 4u : (uint32_t)(T * blk) * 4u);
+                } else {
+                    om[j] = om_mirror ? gload4<AUX>(om_c, lane0 ? o_off + (uint32_t)T * 4u : o_off, mb * 4u)
+                                      : gload4<AUX>(om_c, o_off, (uint32_t)(T * blk) * 4u);
+                }
             }
         }
     }
@@ -905,7 +923,9 @@ struct Pass1 {
 #ifndef OW_P1_PAIRWISE
 #define OW_P1_PAIRWISE 7  // bits: 1 = phase reduction (modulate), 2 = wave numbers, 4 = layer coefficients
 #endif
+    template <int J0 = 0, int J1 = P>
     static OW_DEV void modulate(cplx *h, const cplx *a, const cplx *b, const float *om, float time) {
+        static_assert(J0 % 2 == 0 && J1 % 2 == 0, "texels are modulated two at a time");
 #if OW_DEVICE_BUILD && (OW_P1_PAIRWISE & 1)
         if constexpr (kPairwise) {
             // Texels j and j + 1 together, every value in "one texel per half" layout, so that nothing has to be shuffled between the steps:
@@ -913,7 +933,7 @@ struct Pass1 {
             //   h.re = fma(pp.re, c, -(pp.im s)),  h.im = fma(qq.im, c, qq.re s)   with pp = a + b, qq = a - b, (c, s) = exp(i omega t):
             // exactly the operations -- the two fused products included -- that the one-texel form below compiles to.
 #pragma unroll
-            for (int j = 0; j < P; j += 2) {
+            for (int j = J0; j < J1; j += 2) {
                 // (the FP32-rounded products omega * t of spectrum_modulate.glsl:65: only a multiply and explicit fmas consume them)
                 const cplx ph = cplx{om[j], om[j + 1]} * cplx{time, time};
                 const cplx q = ph * cplx{0.318309886183790672f, 0.318309886183790672f};
@@ -948,7 +968,7 @@ struct Pass1 {
         }
 #endif
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const cplx m = expi_phase(mul_rn(om[j], time));  // (cos, sin)
             // reference: h = h0 * m + conj(h0(-k)) * conj(m) with the texel (a, conj(b)), m = (cs, sn).  Expanded:
             //   h.re = (a.re + b.re) cs - (a.im + b.im) sn ,  h.im = (a.re - b.re) sn + (a.im - b.im) cs
@@ -969,6 +989,34 @@ struct Pass1 {
         float om[P];
         load_raw<AUX>(a, b, om, t, y, h0_c, om_c);
         modulate(h, a, b, om, time);
+    }
+    // LOADS AND MODULATION INTERLEAVED (round 6).  A launch starts with every resident wave issuing its 48 loads at once; the memory pipeline takes them at
+    // the rate the fabric delivers, so a wave spends a fifth of its life stalled AT a load instruction (phase stamps: "loads issued" 11 k of 52 k clocks) --
+    // in order, unable to touch the texels that came back long ago -- and only then modulates (3.7 k clocks of arithmetic on an otherwise idle SIMD).
+    // Here the loads go out four texels at a time and the texels of the chunk before are modulated in between: the arithmetic runs inside the stall.
+    // between(): called once, after the first two chunks are out (the wave-number terms are computed there, under the same stall).  Same operations on
+    // the same values: bit-identical.
+    template <int AUX = 0, class Between>
+    static OW_DEV void pipelined_load_modulate(cplx *h, int t, int y, GBuf h0_c, GBuf om_c, float time, Between between) {
+        cplx a[P], b[P];
+        float om[P];
+        load_raw<AUX, 0, 4>(a, b, om, t, y, h0_c, om_c);
+        OW_SCHED_FENCE();
+        load_raw<AUX, 4, 8>(a, b, om, t, y, h0_c, om_c);
+        OW_SCHED_FENCE();
+        between();
+        OW_SCHED_FENCE();
+        modulate<0, 4>(h, a, b, om, time);
+        OW_SCHED_FENCE();
+        load_raw<AUX, 8, 12>(a, b, om, t, y, h0_c, om_c);
+        OW_SCHED_FENCE();
+        modulate<4, 8>(h, a, b, om, time);
+        OW_SCHED_FENCE();
+        load_raw<AUX, 12, 16>(a, b, om, t, y, h0_c, om_c);
+        OW_SCHED_FENCE();
+        modulate<8, 12>(h, a, b, om, time);
+        OW_SCHED_FENCE();
+        modulate<12, 16>(h, a, b, om, time);
     }
 
     // Wave-vector terms of the lane's 16 texels (spectrum_modulate.glsl:60-62).  kx of slot j is

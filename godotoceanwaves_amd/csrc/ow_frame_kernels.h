@@ -22,6 +22,20 @@
 #ifndef OW_P1_WAVES
 #define OW_P1_WAVES 4
 #endif
+// A/B knobs of the two tick-pair kernels (scripts/build_variant.sh; profiles/EXPERIMENTS.md round 6): wave priority (s_setprio 0 .. 3) of the blocks of
+// either pass, and which pass takes the even chunks of 8 blocks (the ones the dispatcher hands out first)
+#ifndef OW_P1_PIPELINE   // pass 1 (compact family, N >= 1024): loads and modulation interleaved, ow_device.h Pass1::pipelined_load_modulate
+#define OW_P1_PIPELINE 0
+#endif
+#ifndef OW_PAIR_P1_PRIO
+#define OW_PAIR_P1_PRIO 0
+#endif
+#ifndef OW_PAIR_P2_PRIO
+#define OW_PAIR_P2_PRIO 0
+#endif
+#ifndef OW_PAIR_P1_FIRST
+#define OW_PAIR_P1_FIRST 0
+#endif
 namespace ow {
 
 // VAR bits (kbench only; the product instantiates VAR = 0):
@@ -547,18 +561,24 @@ __device__ __forceinline__ void pass1c_item(const DeviceBuffers &buf, const Casc
     const GBuf rrow_c = make_gbuf(buf.rrow + (size_t)tslot * N * 4, (uint32_t)N * 32u);
 
     cplx h[P];
-    {
-        cplx a[P], b[P];
-        float om[P];
-        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
-        issued();
-        Pass1<N>::modulate(h, a, b, om, time);
-    }
-    stamp(1, h[0].x);
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
-    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    if constexpr (OW_P1_PIPELINE && N >= 1024) {  // loads a few texels at a time, the arithmetic in between (Pass1::pipelined_load_modulate); the table after it
+        Pass1<N>::template pipelined_load_modulate<AUX_H>(h, t, y, h0_c, om_c, time, [&] { Pass1<N>::wave_numbers(ik, t, ky, dkx); });
+        issued();
+        stamp(1, h[0].x);
+    } else {
+        {
+            cplx a[P], b[P];
+            float om[P];
+            Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
+            issued();
+            Pass1<N>::modulate(h, a, b, om, time);
+        }
+        stamp(1, h[0].x);
+        Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    }
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     // the wave that holds texel row 0 (its first lane does; for N < 1024 it holds a few more rows, transformed along and
@@ -847,23 +867,34 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
     const int q = tau % ROWS, xi = tau / ROWS;  // xi in [0, T)
     cplx h[P];
     cplx wxi;
-    {
-        SplitTw<SG> twv;
-        split_tw_fetch<SG>(twv, buf.tw_split, tau);
-        wxi = buf.tw_split[SG::TW + xi];
-        cplx a[P], b[P];
-        float om[P];
-        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
-        stamp(1, 0.0f);  // loads issued
-        split_tw_commit<SG>(twv, tw_lds, tau);
-        stamp(2, a[15].x + om[15]);  // table committed (block barrier), own data arrived
-        Pass1<N>::modulate(h, a, b, om, time);
-    }
-    stamp(3, h[15].x);  // modulated
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
-    Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    if constexpr (OW_P1_PIPELINE != 0) {  // loads a few texels at a time, the arithmetic in between (Pass1::pipelined_load_modulate); the table after it
+        SplitTw<SG> twv;
+        split_tw_fetch<SG>(twv, buf.tw_split, tau);
+        wxi = buf.tw_split[SG::TW + xi];
+        Pass1<N>::template pipelined_load_modulate<AUX_H>(h, t, y, h0_c, om_c, time, [&] { Pass1<N>::wave_numbers(ik, t, ky, dkx); });
+        stamp(1, 0.0f);
+        split_tw_commit<SG>(twv, tw_lds, tau);
+        stamp(2, h[15].x);
+        stamp(3, h[15].x);
+    } else {
+        {
+            SplitTw<SG> twv;
+            split_tw_fetch<SG>(twv, buf.tw_split, tau);
+            wxi = buf.tw_split[SG::TW + xi];
+            cplx a[P], b[P];
+            float om[P];
+            Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
+            stamp(1, 0.0f);  // loads issued
+            split_tw_commit<SG>(twv, tw_lds, tau);
+            stamp(2, a[15].x + om[15]);  // table committed (block barrier), own data arrived
+            Pass1<N>::modulate(h, a, b, om, time);
+        }
+        stamp(3, h[15].x);  // modulated
+        Pass1<N>::wave_numbers(ik, t, ky, dkx);
+    }
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     // E[k] +- W_N^k O[k] for k = xi + T m, m = 2g and 2g + 1 (chunk g of four): staged values of row q
@@ -1037,13 +1068,15 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
         constexpr int CL = OW_PAIR_SPLIT_CHUNK_LOG2;
         const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> CL;
         if (index < both) {
-            first = chunk & 1;
+            first = (chunk & 1) != OW_PAIR_P1_FIRST;
             index = ((chunk >> 1) << CL) + (index & ((1 << CL) - 1));
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
         }
     }
+    if (OW_PAIR_P1_PRIO && first) __builtin_amdgcn_s_setprio(OW_PAIR_P1_PRIO);
+    if (OW_PAIR_P2_PRIO && !first) __builtin_amdgcn_s_setprio(OW_PAIR_P2_PRIO);
 #ifdef OW_PAIR_EXPERIMENT
     // tools/kbench_2048pair only (the product never defines OW_PAIR_EXPERIMENT): de-phase the two kinds of block of the launch's FIRST wave generation
     // (blocks below OW_PAIR_EXPERIMENT: the ones resident from the start, which otherwise all issue their load bursts at the same moment) by letting one kind
@@ -1584,13 +1617,15 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     {
         const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
         if (index < both) {
-            first = chunk & 1;
+            first = (chunk & 1) != OW_PAIR_P1_FIRST;
             index = ((chunk >> 1) << 3) + (index & 7);
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
         }
     }
+    if (OW_PAIR_P1_PRIO && first) __builtin_amdgcn_s_setprio(OW_PAIR_P1_PRIO);
+    if (OW_PAIR_P2_PRIO && !first) __builtin_amdgcn_s_setprio(OW_PAIR_P2_PRIO);
     int slot, row0;
     if (!first) {
         constexpr int BPC = N / kWgRows;

@@ -826,11 +826,13 @@ int prearm_launch(ow_context *c, const ow_cascade_params *records, int count, co
     ow_context::Lookahead &la = c->la;
     constexpr int kRing = ow_context::Lookahead::kMaxAhead;
     const int idx = count - 1;
+    if (lookahead_mode(c, 1) != 2) return 0;  // the group kernel's form only; a context whose single cascades take the pair kernel (2048^2 x 1) keeps whatever
+                                              // its last ow_process computed ahead for this update -- that call's own check decides
     if (!flush && la.armed && la.queued > 0) {
         // Work computed ahead is waiting already.  If its head is what the first ow_process of this update will ask for (a regular cadence: the previous
         // update's last ow_process guessed right), leave it.  If it cannot hit -- pair-kernel entries left by ow_update_all, a guess made with another
         // delta -- that call would miss, launch a lone pass 1 and refill: the round-4 path.  Drop the stale queue and pre-arm instead.
-        if (lookahead_mode(c, 1) == 2 && queue_head_serves(c, idx, records[idx])) return 0;
+        if (queue_head_serves(c, idx, records[idx])) return 0;
         la.armed = false;
         la.queued = 0;
     }

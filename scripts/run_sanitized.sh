@@ -1,25 +1,25 @@
 #!/bin/bash
 # Runs the host side of libocean_waves under sanitizers on a GPU box; builds come from scripts/build_sanitized.sh (they travel
-# with the snapshot).  Device code is the shipped code (host-only instrumentation).   OUT=name bash scripts/run_sanitized.sh  -> gpurun_out/$OUT/sanitizers.txt
+# with the snapshot): ow_runtime.hip / ow_group.hip compiled by g++ with GCC's ASan + UBSan / TSan, the kernel units by hipcc as shipped.   OUT=name bash scripts/run_sanitized.sh  -> gpurun_out/$OUT/sanitizers.txt
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=${OUT:-r06_san}; O=gpurun_out/$OUT; mkdir -p $O; export TMPDIR=/tmp
-RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux; V=$PWD/godotoceanwaves_amd/csrc/build/variants
+ASAN_RT=$(gcc -print-file-name=libasan.so); TSAN_RT=$(gcc -print-file-name=libtsan.so); V=$PWD/godotoceanwaves_amd/csrc/build/variants
 R=$O/sanitizers.txt; : > $R
 say() { echo "$@" | tee -a $R; }
 export OW_ASSUME_GPU=1
 # ---- AddressSanitizer + UndefinedBehaviorSanitizer: the runtime (look-ahead queue, scratch ring, run-after-run), the group, readback, interop ----
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:abort_on_error=0:print_summary=1:log_path=$PWD/$O/asan_report
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$PWD/$O/ubsan_report
-ASAN_TESTS="tests/test_lookahead.py tests/test_tick_groups.py tests/test_run_after_run.py tests/test_spectrum_resident.py tests/test_group.py tests/test_readback.py"
-say "== ASan + UBSan (host side; device code unchanged): LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so OCEAN_WAVES_LIB=$V/asan.so ASAN_OPTIONS=$ASAN_OPTIONS"
+ASAN_TESTS="tests/test_lookahead.py tests/test_run_after_run.py tests/test_spectrum_resident.py tests/test_group.py tests/test_readback.py tests/test_tick_groups.py::test_tick_pairs_equal_one_launch_per_pass tests/test_tick_groups.py::test_group_depth_follows_the_run_and_the_scratch_grows_on_first_use"
+say "== ASan + UBSan (host side; device code unchanged): LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so ASAN_OPTIONS=$ASAN_OPTIONS"
 say "   python -m pytest $ASAN_TESTS -m gpu -q"
-LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so OCEAN_WAVES_LIB=$V/asan.so timeout 2400 python -m pytest $ASAN_TESTS -m gpu -q --timeout 1200 -p no:cacheprovider > $O/asan_pytest.log 2>&1
+LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 2400 python -m pytest $ASAN_TESTS -m gpu -q --timeout 1200 -p no:cacheprovider > $O/asan_pytest.log 2>&1
 say "   rc=$?  $(tail -1 $O/asan_pytest.log)"
 say "   python -m pytest tests/test_runtime_contract.py tests/test_interop.py -m gpu -q      (these import torch into the sanitized process)"
-LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so OCEAN_WAVES_LIB=$V/asan.so timeout 1200 python -m pytest tests/test_runtime_contract.py tests/test_interop.py -m gpu -q --timeout 900 -p no:cacheprovider > $O/asan_pytest_torch.log 2>&1
+LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 1200 python -m pytest tests/test_runtime_contract.py tests/test_interop.py -m gpu -q --timeout 900 -p no:cacheprovider > $O/asan_pytest_torch.log 2>&1
 say "   rc=$?  $(tail -1 $O/asan_pytest_torch.log)"
-say "   python scripts/fuzz_schedule.py 4 901     (44 random schedules, merged against never-merging, bit for bit)"
-LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so OCEAN_WAVES_LIB=$V/asan.so timeout 2400 python scripts/fuzz_schedule.py 4 901 > $O/asan_fuzz.log 2>&1
+say "   python scripts/fuzz_schedule.py 3 901     (33 random schedules, merged against never-merging, bit for bit)"
+LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 2400 python scripts/fuzz_schedule.py 3 901 > $O/asan_fuzz.log 2>&1
 say "   rc=$?  $(tail -1 $O/asan_fuzz.log)"
 n=$(ls $O/asan_report* $O/ubsan_report* 2>/dev/null | wc -l)
 say "   sanitizer report files: $n"
@@ -27,11 +27,11 @@ for f in $O/asan_report* $O/ubsan_report*; do [ -f "$f" ] && { say "--- $f"; gre
 # ---- ThreadSanitizer: the group's worker threads (ow_group.hip: one worker per shard, mutex / condition-variable hand-offs) from a compiled C host ----
 export TSAN_OPTIONS=halt_on_error=0:second_deadlock_stack=1:log_path=$PWD/$O/tsan_report:ignore_noninstrumented_modules=1
 say "== TSan: examples/multi_gpu_host.c (compiled C99 host, eight shards, every shard through the peer path, overlapped gathers) against $V/tsan.so"
-/opt/rocm/lib/llvm/bin/clang -O1 -g -std=c99 -fsanitize=thread -shared-libsan -Iinclude examples/multi_gpu_host.c -o /tmp/multi_gpu_host_tsan $V/tsan.so -Wl,-rpath,$V -Wl,-rpath,$RT -Wl,-rpath-link,/opt/rocm/lib -lm >> $R 2>&1
-LD_LIBRARY_PATH=$RT:$LD_LIBRARY_PATH timeout 900 /tmp/multi_gpu_host_tsan 512 1 120 8 0,0,0,0,0,0,0,0 peer > $O/tsan_host.log 2>&1
+gcc -O1 -g -std=c99 -fsanitize=thread -Iinclude examples/multi_gpu_host.c -o /tmp/multi_gpu_host_tsan $V/tsan.so -Wl,-rpath,$V -Wl,-rpath-link,/opt/rocm/lib -lm >> $R 2>&1
+timeout 900 /tmp/multi_gpu_host_tsan 512 1 120 8 0,0,0,0,0,0,0,0 peer > $O/tsan_host.log 2>&1
 say "   rc=$?  $(tail -1 $O/tsan_host.log | cut -c1-200)"
-say "   python -m pytest tests/test_group.py -m gpu -q  under LD_PRELOAD=libclang_rt.tsan (python itself uninstrumented: ignore_noninstrumented_modules=1)"
-LD_PRELOAD=$RT/libclang_rt.tsan-x86_64.so OCEAN_WAVES_LIB=$V/tsan.so timeout 1500 python -m pytest tests/test_group.py -m gpu -q --timeout 900 -p no:cacheprovider > $O/tsan_pytest.log 2>&1
+say "   python -m pytest tests/test_group.py -m gpu -q -k 'not c4_exact_shape'  under LD_PRELOAD=$TSAN_RT (python itself uninstrumented: ignore_noninstrumented_modules=1; the C4 test spends its time in the OpenMP oracle)"
+LD_PRELOAD=$TSAN_RT OCEAN_WAVES_LIB=$V/tsan.so timeout 1500 python -m pytest tests/test_group.py -m gpu -q -k "not c4_exact_shape" --timeout 600 -p no:cacheprovider > $O/tsan_pytest.log 2>&1
 say "   rc=$?  $(tail -1 $O/tsan_pytest.log)"
 n=$(ls $O/tsan_report* 2>/dev/null | wc -l)
 say "   TSan report files: $n"

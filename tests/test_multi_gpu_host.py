@@ -43,6 +43,10 @@ def test_c_program_and_python_group_agree(tmp_path, devices, per):
     r = subprocess.run([build(tmp_path), str(n), str(per), str(ticks), str(every), devices], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
+    # round 6: one line per shard first -- how its layers reach the root device (ow_group_link_info: peer access, link type, hops, which path)
+    links = [l for l in lines if l.startswith("shard ")]
+    assert len(links) == len(devices.split(",")) and all("device 0 -> root device 0: same device, peer_access=1" in l for l in links)
+    lines = [l for l in lines if not l.startswith("shard ")]
     assert lines[0].startswith("model: per-device tick") and "153 GB/s per link" in lines[0]   # the model the first real multi-GPU run is read against
     out = dict(kv.split("=") for kv in lines[-1].split())
     shards = len(devices.split(","))
