@@ -718,6 +718,9 @@ struct TickGroupArgs {
                                      //   ANOTHER set of cascades at the same tick -- the cascades the reference's next ow_process calls will take)
     int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
+    int32_t interleave;              // plain form only: the blocks of the two passes alternate in chunks of 8 (as in the tick-pair kernels) instead of all pass-2
+                                     // blocks first -- for the look-ahead's launches of ONE tick of pass 2 beside pass 1 of later ones, where either kind fills the
+                                     // chip by itself and the launch otherwise lasts as long as the two after each other (both block counts multiples of 8)
 };
 // One launch of the TICK-PAIR kernels (k_tick_pair_c, k_tick_pair_c_split) -- pass 2 of one batch, pass 1 of the next -- needs one row of
 // times, two scratch bases and the two block counts: 256 bytes with the cascades' constants instead of FrameArgs + TickGroupArgs' 950
@@ -1519,7 +1522,9 @@ OW_DEV float omega_texel(int x, int y, int n, float tile_x, float tile_y, float 
     const float kx = modulate_kcomp(x, n, tile_x), ky = modulate_kcomp(y, n, tile_y);
     const float k = sqrtf(kx * kx + ky * ky) + 1e-6f;
     const float a = k * depth;
-    const float b = (float)tanh((double)a);  // correctly rounded tanhf
+    // correctly rounded tanhf -- which is exactly 1.0f from a = 9.02 on (1 - tanh a = 2 / (e^2a + 1) < 2^-25 there): the FP64 evaluation only for the
+    // few texels around DC that need it (a wave-uniform skip almost everywhere)
+    const float b = a > 9.1f ? 1.0f : (float)tanh((double)a);
     return sqrtf(kG * k * b);
 }
 
@@ -1528,9 +1533,9 @@ OW_DEV void hash_uniform(uint32_t x, uint32_t y, float &u1, float &u2) {  // spe
     h32 = 2246822519u * (h32 ^ (h32 >> 15));
     h32 = 3266489917u * (h32 ^ (h32 >> 13));
     const uint32_t n = h32 ^ (h32 >> 16), n2 = n * 48271u;
-    const float den = 2147483648.0f;  // float(0x7FFFFFFF)
-    u1 = (float)((n >> 1) & 0x7FFFFFFFu) / den;
-    u2 = (float)((n2 >> 1) & 0x7FFFFFFFu) / den;
+    const float rden = 1.0f / 2147483648.0f;  // 1 / float(0x7FFFFFFF): float(0x7FFFFFFF) rounds to 2^31, and a division by a power of two IS this product
+    u1 = (float)((n >> 1) & 0x7FFFFFFFu) * rden;
+    u2 = (float)((n2 >> 1) & 0x7FFFFFFFu) * rden;
 }
 
 OW_DEV cplx spectrum_amplitude(int idx, int idy, int n, const SpectrumPC &pc) {  // spectrum_compute.glsl:103-115
@@ -1572,6 +1577,79 @@ OW_DEV cplx spectrum_amplitude(int idx, int idy, int n, const SpectrumPC &pc) { 
     const float rr = sqrtf(-2.0f * logf(u1)), th = (2.0f * kPi) * u2;
     const float amp = sqrtf(2.0f * s * d * w_norm);
     return cplx{rr * cosf(th) * amp, rr * sinf(th) * amp};
+}
+
+// THE SAME AMPLITUDE AT HALF THE INSTRUCTIONS (round 6; the kernel's form -- the literal one above stays the CPU build's, bit-equal to the oracle).
+// k_spectrum is pure arithmetic (2 000 vector instructions per texel, 56 us per 1024^2 cascade: the only kernel of the path at 3 % of the roofline), and
+// most of it is generality the formulas do not need: five powf -- two with the integer exponents 5 and 4, one with the constant base 3.3, two with positive
+// bases, for which exp2(e log2 x) on the hardware's 1-ulp v_exp_f32 / v_log_f32 is exact to ~1e-6 at the exponents that occur --, sinf / cosf with their
+// huge-argument paths for the Box-Muller angle in [0, 2 pi) (the frame kernels' Cody-Waite sincos: 1.3e-7 absolute, on a factor of the amplitude), IEEE division
+// sequences where 2-ulp reciprocals do, a division by 2^31, and tanh(k depth), which IS 1.0f from k depth = 9.02 on (1 - tanh a < 2^-25), i.e. for all
+// but a few texels around DC at the reference's depth of 20 m.  h0 stays within the 2e-5 the parity tests allow against the oracle (measured on the CPU
+// build, tests/test_emul.py: <= 3e-6 over the presets; the GPU's native exp2 / log2 add an ulp each).  omega is untouched (omega_texel: bit-exact).
+OW_DEV float fast_exp2(float x) {
+#if OW_DEVICE_BUILD
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
+OW_DEV float fast_log2(float x) {
+#if OW_DEVICE_BUILD
+    return __builtin_amdgcn_logf(x);  // v_log_f32: log2
+#else
+    return log2f(x);
+#endif
+}
+OW_DEV float pow_pos(float x, float e) {  // x >= 0; x^0 = 1 (also for x = 0, as powf)
+    return e == 0.0f ? 1.0f : fast_exp2(e * fast_log2(x));
+}
+OW_DEV float tanh_sat(float a) {  // tanhf(a) for a >= 0: exactly 1 where the correctly rounded value is
+    return a > 9.1f ? 1.0f : tanhf(a);
+}
+OW_DEV cplx spectrum_amplitude_fast(int idx, int idy, int n, const SpectrumPC &pc) {  // spectrum_compute.glsl:103-115, operation for operation up to the items above
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const float dkx = (2.0f * kPi) * fast_rcp(pc.tile_x), dky = (2.0f * kPi) * fast_rcp(pc.tile_y);
+    const float half = (float)n * 0.5f;
+    const float kx = ((float)idx - half) * dkx, ky = ((float)idy - half) * dky;
+    const float k = sqrtf(kx * kx + ky * ky) + 1e-6f;
+    const float theta = atan2f(kx, ky);
+    // dispersion_relation (:58-66)
+    const float a = k * pc.depth, b = tanh_sat(a);
+    const float w = sqrtf(kG * k * b), rw = fast_rcp(w);
+    const float dw = (0.5f * kG) * (b + a * (1.0f - b * b)) * rw;
+    const float w_norm = dw * fast_rcp(k) * dkx * dky;
+    // TMA_spectrum (:89-101)
+    const float w_p = pc.peak_frequency;
+    const float sigma = (w <= w_p) ? 0.07f : 0.09f;
+    const float r = expf(-(w - w_p) * (w - w_p) * fast_rcp(2.0f * sigma * sigma * w_p * w_p));
+    const float w2 = w * w, q = w_p * rw, q2 = q * q;
+    const float jonswap = (pc.alpha * kG * kG) * fast_rcp(w2 * w2 * w) * expf(-1.25f * (q2 * q2)) * fast_exp2(r * 1.7224660244710912f);  // 3.3^r
+    const float w_h = fminf(w * sqrtf(pc.depth * (1.0f / kG)), 2.0f);
+    const float kit = (w_h <= 1.0f) ? 0.5f * w_h * w_h : 1.0f - 0.5f * (2.0f - w_h) * (2.0f - w_h);
+    const float s = jonswap * kit;
+    // hasselmann_directional_spread (:81-86) + longuet_higgins (:69-78)
+    const float pr = fabsf(w * fast_rcp(w_p));
+    float sh = (w <= w_p) ? 6.97f * pow_pos(pr, 4.06f) : 9.77f * pow_pos(pr, -2.33f - 1.45f * (pc.wind_speed * w_p * (1.0f / kG) - 1.17f));
+    sh = sh + 16.0f * tanhf(q) * pc.swell * pc.swell;
+    const float sq = sqrtf(sh);
+    const float lh_norm = (sh < 0.4f) ? (0.5f / kPi) + sh * (0.220636f + sh * (-0.109f + sh * 0.090f))
+                                      : (1.0f / sqrtf(kPi)) * (sq * 0.5f + fast_rcp(sq) * 0.0625f);
+    // (the general cosf here: where theta - angle passes pi the cosine goes through zero and |cos|^(2 sh) with a small exponent turns its RELATIVE error
+    //  into the result's -- 8 % at the texel straight downwind of a -270 degree wind with the 1.3e-7-absolute sincos_phase; tests/test_emul.py)
+    const float hd = lh_norm * pow_pos(fabsf(cosf((theta - pc.angle) * 0.5f)), 2.0f * sh);
+    const float am = 1.0f - pc.spread;
+    const float d = ((0.5f / kPi) * (1.0f - am) + hd * am) * expf(-(1.0f - pc.detail) * (1.0f - pc.detail) * k * k);
+    // gaussian(hash(id + seed)) (:44-49)
+    float u1, u2;
+    hash_uniform((uint32_t)(idx + pc.seed_x), (uint32_t)(idy + pc.seed_y), u1, u2);  // (its division by 2^31 is exact either way)
+    const float rr = sqrtf(-2.0f * logf(u1)), th = (2.0f * kPi) * u2;
+    float sn, cs;
+    sincos_phase(th, sn, cs);
+    const float amp = sqrtf(2.0f * s * d * w_norm);
+    return cplx{rr * cs * amp, rr * sn * amp};
 }
 
 // The reference texel (spectrum_compute.glsl:117-125) is (amplitude(id), conj(amplitude(mod(-id, dims)))); only

@@ -1537,8 +1537,21 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
             return;
         }
     }
-    if (!PIPE && (int)blockIdx.x < g.n2) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
-        const int item = blockIdx.x;
+    // which pass this block works for, and its index there: pass-2 blocks first -- or, g.interleave, alternating with the pass-1 blocks in chunks of 8
+    int bx = blockIdx.x;
+    bool second = bx < g.n2;
+    if (!PIPE && g.interleave) {
+        const int n1t = g.d1 * g.n1, both = 2 * (g.n2 < n1t ? g.n2 : n1t), chunk = bx >> 3;
+        if (bx < both) {
+            second = !(chunk & 1);
+            bx = ((chunk >> 1) << 3) + (bx & 7) + (second ? 0 : g.n2);
+        } else {
+            second = g.n2 > n1t;
+            bx = bx - both / 2 + (second ? 0 : g.n2);
+        }
+    }
+    if (!PIPE && second) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
+        const int item = bx;
         const int slot = item / (N / ROWS), row0 = (item % (N / ROWS)) * ROWS;
         const CascadeFrame cf = args.c[slot];  // (pass 2 does not use the time)
         fetch_arguments(buf, cf);
@@ -1560,7 +1573,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
         return;
     }
     // ---- pass 1: tick j of the later group ----
-    const int b1 = (int)blockIdx.x - g.n2, j = b1 / g.n1, item = b1 % g.n1;
+    const int b1 = bx - g.n2, j = b1 / g.n1, item = b1 % g.n1;
     const int tau = threadIdx.x;
     const int sub = __builtin_amdgcn_readfirstlane(tau / SUB), tau_sub = tau % SUB;
     if (g.p1_compact) {  // (launch-uniform) Q 8-row items side by side, each doing all its layers (k_pass1c's body): no redundant modulation

@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void k_spectrum(int n, int cascade, SpectrumPC
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= n || y >= n) return;
     const size_t idx = ((size_t)cascade * n + y) * n + x;
-    buf.h0[idx] = spectrum_amplitude(x, y, n, pc);  // the texel's .zw is the mirrored texel's .xy, conjugated: not stored
+    buf.h0[idx] = spectrum_amplitude_fast(x, y, n, pc);  // the texel's .zw is the mirrored texel's .xy, conjugated: not stored
     buf.omega[idx] = omega_texel(x, y, n, pc.tile_x, pc.tile_y, pc.depth);
 }
 

@@ -34,12 +34,36 @@ fi
 if want san; then
 OUT=$OUT bash scripts/run_sanitized.sh > $O/san_stdout.log 2>&1; tail -70 $O/san_stdout.log
 fi
+if want tsan; then
+OUT=$OUT ONLY_TSAN=1 bash scripts/run_sanitized.sh > $O/tsan_stdout.log 2>&1; tail -40 $O/tsan_stdout.log
+fi
 if want scene; then   # the scene's cadence under a kernel trace: launches per update, and what each costs
 rm -rf $O/scene_trace
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/scene_trace" -o t -- python "$GRAFT_REPO_ROOT/scripts/scene_probe.py" --hz 144) > $O/scene_probe_144.log 2>&1
 python scripts/rocprof_summary.py $O/scene_trace $O/scene_kernel_trace_144hz.txt; grep "per update" $O/scene_probe_144.log; head -8 $O/scene_kernel_trace_144hz.txt | cut -c1-160
 rm -rf $O/scene_trace
 timeout 300 python scripts/scene_probe.py --hz 60 | grep "per update"
+fi
+if want sceneab; then   # the look-ahead's launches with their blocks interleaved (1) or pass 2 first (0): knobs build, alternating processes
+K=godotoceanwaves_amd/csrc/build/variants/knobs.so; : > $O/sceneab.txt
+for rep in 1 2 3; do for v in 0 1; do
+  echo "== interleave=$v (rep $rep)" >> $O/sceneab.txt
+  for hz in 144 60; do OW_DEBUG_LA_INTERLEAVE=$v OCEAN_WAVES_LIB=$PWD/$K timeout 300 python scripts/scene_probe.py --hz $hz 2>&1 | grep "per update" | cut -c1-110 >> $O/sceneab.txt; done
+  for cfg in "1024 4 reference" "512 4 reference" "256 4 reference" "1024 1 reference" "256 4 calls" "512 4 calls" "1024 1 calls"; do
+    echo -n "   $cfg: " >> $O/sceneab.txt; OW_DEBUG_LA_INTERLEAVE=$v OCEAN_WAVES_LIB=$PWD/$K timeout 300 python scripts/lookahead_ab.py --child $cfg 2>&1 | tail -1 >> $O/sceneab.txt
+  done
+done; done
+cat $O/sceneab.txt
+fi
+if want spectrum; then   # k_spectrum under a kernel trace, and its parity tests
+timeout 900 python -m pytest "tests/test_gpu_parity.py" -m gpu -q -k "spectrum or dirty or edges" --timeout 600 > $O/pytest_spectrum.log 2>&1; tail -3 $O/pytest_spectrum.log
+rm -rf $O/spec_trace
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/spec_trace" -o t -- python "$GRAFT_REPO_ROOT/scripts/drive.py" --map-size 1024 --cascades 8 --frames 4) > $O/spec_trace.log 2>&1
+python scripts/rocprof_summary.py $O/spec_trace $O/spectrum_kernel_trace.txt; grep -i "spectrum" $O/spectrum_kernel_trace.txt | cut -c1-120
+rm -rf $O/spec_trace
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/spec_trace" -o t -- python "$GRAFT_REPO_ROOT/scripts/drive.py" --map-size 2048 --cascades 4 --frames 4) > $O/spec_trace.log 2>&1
+python scripts/rocprof_summary.py $O/spec_trace $O/spectrum_kernel_trace_2048.txt; grep -i "spectrum" $O/spectrum_kernel_trace_2048.txt | cut -c1-120
+rm -rf $O/spec_trace
 fi
 if want hash; then
 timeout 900 python scripts/hash_maps.py ${HASH_BUILDS} > $O/hash_maps.txt 2>&1; cat $O/hash_maps.txt

@@ -416,6 +416,16 @@ void emul_spectrum(int n, const SpectrumPC *pc, float *h0, float *h0a, float *om
         }
 }
 
+// the kernel's form of the amplitude (spectrum_amplitude_fast: cheaper evaluation of the same formulas), n*n complex
+void emul_spectrum_fast(int n, const SpectrumPC *pc, float *h0a) {
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            const cplx a = spectrum_amplitude_fast(x, y, n, *pc);
+            h0a[((size_t)y * n + x) * 2 + 0] = a.x;
+            h0a[((size_t)y * n + x) * 2 + 1] = a.y;
+        }
+}
+
 // one frame of one cascade: h0 = the stored half-spectrum plane (n*n complex); Tbuf = 4*n*n*2 floats (device layout, see t_unit); foam = n*n halves (device layout,
 // Pass2::foam_index) is the recurrent state, read and rewritten; norm is written
 int emul_frame(int n, const float *h0a, const float *omega, const CascadeFrame *cf, float *Tbuf, uint16_t *disp,

@@ -39,11 +39,37 @@ def emul():
     E.emul_rows_fft.argtypes = [C.c_int, f32p, f32p, C.c_int]
     E.emul_rows_fft_half_table.argtypes = [f32p, f32p, C.c_int]
     E.emul_spectrum.argtypes = [C.c_int, C.POINTER(PC), f32p, f32p, f32p]
+    E.emul_spectrum_fast.argtypes = [C.c_int, C.POINTER(PC), f32p]
     E.emul_frame.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_frame_compact.argtypes = [C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_frame_lp.argtypes = [C.c_int, C.c_int, f32p, f32p, C.POINTER(CF), f32p, u16p, u16p, u16p, f32p]
     E.emul_sincos.argtypes = [C.c_int, f32p, f32p, f32p]
     return E
+
+
+def _spectrum_cases():
+    from edge_presets import edge_presets
+    return [(f"preset{i}", cascade_preset(i)) for i in range(8)] + sorted(edge_presets().items())
+
+
+@pytest.mark.parametrize("name,p", _spectrum_cases(), ids=[k for k, _ in _spectrum_cases()])
+def test_the_kernels_cheaper_amplitude_stays_within_the_parity_budget(emul, name, p):
+    """k_spectrum evaluates the reference's formulas in a cheaper form (ow_device.h spectrum_amplitude_fast: integer powers by multiplication, the
+    three other powf as exp2(e log2 x), Cody-Waite sincos, reciprocals for the divisions, tanh saturated to 1 where it rounds to 1).  On the CPU
+    build -- the same code over glibc's exp2f / log2f -- its h0 stays within a QUARTER of the 2e-5 the GPU parity tests allow against the oracle
+    (tests/test_gpu_parity.py test_spectrum_and_omega), over the eight presets and every range-end preset; the GPU's 1-ulp v_exp_f32 / v_log_f32 add
+    an ulp each, amplified by the same exponents.  The literal form (spectrum_amplitude) stays bit-equal to the oracle: test_frame_matches_oracle."""
+    n = 256
+    pc = H.spectrum_pc(p)
+    epc = PC(p["spectrum_seed"][0], p["spectrum_seed"][1], p["tile_length"][0], p["tile_length"][1], pc.alpha, pc.peak_frequency,
+             pc.wind_speed, pc.angle, DEPTH, p["swell"], p["detail"], p["spread"])
+    fast = np.zeros((n, n, 2), np.float32)
+    emul.emul_spectrum_fast(n, C.byref(epc), fast)
+    ref = O.spectrum_compute(n, pc)[..., :2]
+    assert np.isfinite(fast).all()
+    err = H.relmax(fast, ref)
+    print(f"{name}: h0 of the cheaper form vs the oracle {err:.2e}")
+    assert err < 5e-6
 
 
 def test_sincos_phase_accuracy(emul):
