@@ -401,9 +401,9 @@ def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, senso
         bpt = 72 - (4 * (depth - 1) / depth if fam == "tick_groups_compact" and depth > 1 else 0)  # (foam stays in registers between the ticks of a group)
         gbps = bpt * n * n * C / tick / 1e9
         clk = Sensors.summary(smp) or {}
+        # (kept short: eleven of these ride in the one JSON line.  value = maps/s; frac = bytes_per_texel x texels / tick / 8 TB/s)
         return {"workload": f"{n}^2 x {C}", "steps_per_region": steps, "repeats": len(samples), "ms_per_step": round(tick * 1e3, 5),
-                "value": round(C / tick, 1), "unit": "maps/s", "kernel": kernel, "bytes_per_texel": round(bpt, 2), "achieved": round(gbps, 1),
-                "frac": round(gbps / HBM_PEAK_GBPS, 4), "ms_per_step_min_max": [round(min(samples) / steps * 1e3, 5), round(max(samples) / steps * 1e3, 5)],
+                "value": round(C / tick, 1), "kernel": kernel, "bytes_per_texel": round(bpt, 2), "frac": round(gbps / HBM_PEAK_GBPS, 4),
                 "clocks": {k: clk[k] for k in ("sclk_mhz", "power_w") if k in clk}}
     finally:
         drv.free()
@@ -818,8 +818,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
            "foam_bytes": 2 * n * n * C, "maps_bytes": 16 * n * n * C, "infinity_cache_bytes": 256 << 20}
     res["reused_bytes"] = res["spectra_bytes"] + res["intermediate_bytes"] + res["foam_bytes"]
     res["reused_fits_infinity_cache"] = res["reused_bytes"] <= res["infinity_cache_bytes"]
-    res["note"] = ("spectra, intermediate and foam are re-read every tick; the output maps are write-only streams (stored non-temporally). "
-                   "Where the re-read set fits the Infinity Cache the achieved rates are fabric-side (cache + DRAM), not DRAM-only, traffic.")
+    res["note"] = "where the re-read set (spectra, intermediate, foam) fits the Infinity Cache the rates are fabric-side (cache + DRAM) traffic"
     frac_of = lambda seconds: round(gbps((k1 + k2) * n * n * C, seconds / ticks * 1e3) / HBM_PEAK_GBPS, 4)
     clocks = None
     if world == 1:
@@ -857,8 +856,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
                    "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
                    "launches": (f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp)"
                                 if launch_mode == "tick_groups_compact" else
-                                "tick pairs: pass 2 of one batch and pass 1 of the next (the same cascades one tick later, or the tick's other cascades) in one launch (k_tick_pair_c)") +
-                               "; pass1_ms / pass2_ms below are those of the same ticks launched one pass at a time" if grouped
+                                "tick pairs: pass 2 of one batch and pass 1 of the next in one launch (k_tick_pair_c)") if grouped
                                else "one pair of launches per batch and tick",
                    "gather": (f"{args.gather}, every {gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
                              if (world > 1 and gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
@@ -876,12 +874,11 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             **({"clocks": clocks} if clocks is not None else {}),
             **({"update_all_calls": {"ms_per_step": round(calls / ticks * 1e3, 5), "value": round(maps / calls, 2), "unit": "maps/s",
                                      "lookahead_hit_rate": round(calls_hits, 4), "frac": frac_of(calls),
-                                     "launches": "one ow_update_all per tick (OW_FLAG_RUN_AS_CALLS): the tick-by-tick caller, with ow_update_all's adaptive look-ahead "
-                                                 "(a speculated pass 1 of the next tick rides with pass 2 once two deltas in a row were equal)"}}
+                                     "launches": "one ow_update_all per tick (OW_FLAG_RUN_AS_CALLS), its adaptive look-ahead on"}}
                if calls is not None else ({"update_all_calls": {"error": calls_error}} if calls_error else {})),
             **({"unmerged": {"ms_per_step": round(unmerged / ticks * 1e3, 5), "value": round(maps / unmerged, 2), "unit": "maps/s",
                              "frac": frac_of(unmerged),
-                             "launches": "one launch per pass and batch (OW_FLAG_NO_TICK_GROUPS): what callers with an irregular cadence get",
+                             "launches": "one launch per pass and batch (OW_FLAG_NO_TICK_GROUPS)",
                              "ms_per_step_min_max": [round(min(unmerged_samples) / ticks * 1e3, 5), round(max(unmerged_samples) / ticks * 1e3, 5)],
                              "bytes_per_texel": k1 + k2, "achieved": round(gbps((k1 + k2) * n * n * C, unmerged / ticks * 1e3), 1),
                              "frac_of_copy_ceiling": round(gbps((k1 + k2) * n * n * C, unmerged / ticks * 1e3) / COPY_CEILING_GBPS, 4),
@@ -892,14 +889,12 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
                if unmerged is not None else ({"unmerged": {"error": unmerged_error}} if unmerged_error else {})),
             **({"reference_schedule": ({"ms_per_step": round(refsched["seconds"] / ticks * 1e3, 5), "value": round(maps / refsched["seconds"], 2), "unit": "maps/s",
                                          "lookahead_hit_rate": round(refsched["hit_rate"], 4), "frac": frac_of(refsched["seconds"]),
-                                         "cadence": "REGULAR (every update the same delta: the look-ahead into the next update arms); the scene's own cadence is scene_schedule",
-                                         "launches": "per tick one ow_update and one ow_process per cascade (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE: wave_generator.gd:56-63,90-109 "
-                                                     "call by call); an ow_process carries pass 1 of up to four of the cascades the next calls will take, which then launch pass 2 alone"}
+                                         "cadence": "regular (every update the same delta); the scene's own cadence is scene_schedule",
+                                         "launches": "per tick one ow_update + one ow_process per cascade (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE)"}
                                         if "seconds" in refsched else refsched)} if refsched else {}),
             "bytes_per_texel": dom_bpt, "bytes_per_launch": int(dom_bpt * texels),
-            "bytes_basis": "bytes the launched kernel family must move (bench.py FAMILY_BYTES, DESIGN.md section 3)" +
-                           (f"; one launch = both passes of {max(1, group_depth)} tick(s) of {per_launch} cascade(s); its average duration = the timed region / its launches "
-                            "(back to back on one in-order stream)" if grouped else ""),
+            "bytes_basis": "design bytes of the launched kernel family (DESIGN.md section 3)" +
+                           (f"; one launch = both passes of {max(1, group_depth)} tick(s) of {per_launch} cascade(s), duration = timed region / launches" if grouped else ""),
             "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBPS, 4), "copy_ceiling": COPY_CEILING_GBPS,
             # SURVEY 8d's contract bytes (four-layer FP32 intermediate, 104 B/texel per map) over the same duration: a
             # figure of merit against a design that moves more, NOT a bandwidth (it can exceed the copy ceiling)
@@ -1021,9 +1016,9 @@ def main():
                 try:
                     got, detail = measure_traffic(n, C, rf["kernel"], seamless=rf["kernel"].startswith("k_tick_pair_c") and rf["cascades_per_launch"] == C)
                     rf["traffic"] = got
-                    rf["traffic_source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over scripts/drive.py, 80 ticks "
-                                            "through ow_run; FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch (every pair launch of a single-batch run carries both passes); between the XCD L2s and the "
-                                            "fabric, Infinity-Cache hits included")
+                    # (FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch -- every pair launch of a single-batch run carries both passes --
+                    #  between the XCD L2s and the fabric, Infinity-Cache hits included: DESIGN.md section 6)
+                    rf["traffic_source"] = "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, 81 ticks through ow_run), gfx950 correction applied"
                     rf["traffic_detail"] = detail
                     rf["traffic_bytes_per_texel"] = round(got / max(1, rf["bytes_per_launch"]) * rf["bytes_per_texel"], 2)
                     rf["traffic_gbps"] = round(got / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)

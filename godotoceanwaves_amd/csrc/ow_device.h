@@ -718,9 +718,6 @@ struct TickGroupArgs {
                                      //   ANOTHER set of cascades at the same tick -- the cascades the reference's next ow_process calls will take)
     int32_t p2_pipe;                 // pass-2 blocks in the pipelined form (half the columns, the two halves of the block on alternate ticks)
     int32_t p1_compact;              // pass-1 items in k_pass1c's form (8 rows, all layers) instead of the layer-parallel form
-    int32_t interleave;              // plain form only: the blocks of the two passes alternate in chunks of 8 (as in the tick-pair kernels) instead of all pass-2
-                                     // blocks first -- for the look-ahead's launches of ONE tick of pass 2 beside pass 1 of later ones, where either kind fills the
-                                     // chip by itself and the launch otherwise lasts as long as the two after each other (both block counts multiples of 8)
 };
 // One launch of the TICK-PAIR kernels (k_tick_pair_c, k_tick_pair_c_split) -- pass 2 of one batch, pass 1 of the next -- needs one row of
 // times, two scratch bases and the two block counts: 256 bytes with the cascades' constants instead of FrameArgs + TickGroupArgs' 950
@@ -873,7 +870,9 @@ struct Pass1 {
     // b_wrap: lane 0 of a row pairs x = 0 with x = 0 (not with x = N).
     // load_raw issues the loads (a = h0(k), b = the mirrored texel, om = omega); modulate consumes them.  Apart they let a kernel
     // put other work -- the twiddle table's way into LDS and its barrier -- between issue and first use.
-    // (J0 .. J1 - 1: the FFT slots whose texels are asked for -- the pipelined form of the pass-1 items issues them a few at a time, pipelined_load_modulate)
+    // (J0 .. J1 - 1: the FFT slots whose texels are asked for.  Issuing them four at a time with the modulation of the previous four in between -- so that
+    //  the arithmetic runs inside the load-issue stall of a launch's first wave generation -- was measured in round 6: nothing at 2048^2 x 4, 0.8 % slower at
+    //  1024^2 x 4; profiles/r06_ab_kernel_variants.txt.)
     template <int AUX = 0, int J0 = 0, int J1 = P>
     static OW_DEV void load_raw(cplx *a, cplx *b, float *om, int t, int y, GBuf h0_c, GBuf om_c) {
         const int ym = (N - y) % N;
@@ -992,34 +991,6 @@ struct Pass1 {
         float om[P];
         load_raw<AUX>(a, b, om, t, y, h0_c, om_c);
         modulate(h, a, b, om, time);
-    }
-    // LOADS AND MODULATION INTERLEAVED (round 6).  A launch starts with every resident wave issuing its 48 loads at once; the memory pipeline takes them at
-    // the rate the fabric delivers, so a wave spends a fifth of its life stalled AT a load instruction (phase stamps: "loads issued" 11 k of 52 k clocks) --
-    // in order, unable to touch the texels that came back long ago -- and only then modulates (3.7 k clocks of arithmetic on an otherwise idle SIMD).
-    // Here the loads go out four texels at a time and the texels of the chunk before are modulated in between: the arithmetic runs inside the stall.
-    // between(): called once, after the first two chunks are out (the wave-number terms are computed there, under the same stall).  Same operations on
-    // the same values: bit-identical.
-    template <int AUX = 0, class Between>
-    static OW_DEV void pipelined_load_modulate(cplx *h, int t, int y, GBuf h0_c, GBuf om_c, float time, Between between) {
-        cplx a[P], b[P];
-        float om[P];
-        load_raw<AUX, 0, 4>(a, b, om, t, y, h0_c, om_c);
-        OW_SCHED_FENCE();
-        load_raw<AUX, 4, 8>(a, b, om, t, y, h0_c, om_c);
-        OW_SCHED_FENCE();
-        between();
-        OW_SCHED_FENCE();
-        modulate<0, 4>(h, a, b, om, time);
-        OW_SCHED_FENCE();
-        load_raw<AUX, 8, 12>(a, b, om, t, y, h0_c, om_c);
-        OW_SCHED_FENCE();
-        modulate<4, 8>(h, a, b, om, time);
-        OW_SCHED_FENCE();
-        load_raw<AUX, 12, 16>(a, b, om, t, y, h0_c, om_c);
-        OW_SCHED_FENCE();
-        modulate<8, 12>(h, a, b, om, time);
-        OW_SCHED_FENCE();
-        modulate<12, 16>(h, a, b, om, time);
     }
 
     // Wave-vector terms of the lane's 16 texels (spectrum_modulate.glsl:60-62).  kx of slot j is

@@ -134,7 +134,6 @@ static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const D
     g.n1 = g.p1_compact ? TP::items_1_compact(g.slots) : TP::items_1(g.slots);
     const int blocks = g.n2 + g.d1 * g.n1;
     if (blocks < 1) return hipErrorInvalidValue;
-    if (g.p2_pipe || g.d2 < 1 || g.d1 < 1 || (g.n2 & 7) || ((g.d1 * g.n1) & 7)) g.interleave = 0;  // (chunks of 8 blocks of either kind)
     if (g.p2_pipe) launch(k_tick_group_c_lp<N, F32, false, true>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
     else launch(k_tick_group_c_lp<N, F32>, dim3(blocks), dim3(plan_lp_threads(N)), s, lt, buf, args, g, (Stamp *)nullptr);
     return hipGetLastError();

@@ -22,20 +22,6 @@
 #ifndef OW_P1_WAVES
 #define OW_P1_WAVES 4
 #endif
-// A/B knobs of the two tick-pair kernels (scripts/build_variant.sh; profiles/EXPERIMENTS.md round 6): wave priority (s_setprio 0 .. 3) of the blocks of
-// either pass, and which pass takes the even chunks of 8 blocks (the ones the dispatcher hands out first)
-#ifndef OW_P1_PIPELINE   // pass 1 (compact family, N >= 1024): loads and modulation interleaved, ow_device.h Pass1::pipelined_load_modulate
-#define OW_P1_PIPELINE 0
-#endif
-#ifndef OW_PAIR_P1_PRIO
-#define OW_PAIR_P1_PRIO 0
-#endif
-#ifndef OW_PAIR_P2_PRIO
-#define OW_PAIR_P2_PRIO 0
-#endif
-#ifndef OW_PAIR_P1_FIRST
-#define OW_PAIR_P1_FIRST 0
-#endif
 namespace ow {
 
 // VAR bits (kbench only; the product instantiates VAR = 0):
@@ -69,9 +55,9 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef OW_ROWSYNC_FREE_POLLS
 #define OW_ROWSYNC_FREE_POLLS 0
 #endif
-// BLOCK (N = 2048 only; A/B builds, OW_P2_PAIR_BLOCK_BARRIER): the rendezvous is the workgroup's LDS barrier instead -- no spin, no bounded wait, no
-// status report (a barrier cannot give up), every wave of the block in step at every exchange; only where all waves of the block run the same sequence
-template <int N, bool BLOCK = false>
+// (The workgroup's LDS barrier in the 8-wave blocks of the 2048^2 pair kernel instead -- 1 000 fewer instructions, no spin -- was measured in round 6
+//  and is SLOWER: 59 - 62 against 56 - 60 us per cascade, profiles/r06_2048_pair_variants_rejected.txt.)
+template <int N>
 struct RowSync {
     typedef __attribute__((address_space(3))) int lds_int;
     volatile lds_int *mine = nullptr, *partner = nullptr;
@@ -93,9 +79,7 @@ struct RowSync {
         }
     }
     __device__ __forceinline__ void sync() {
-        if constexpr (BLOCK && plan_row_spans_waves(N)) {
-            lds_barrier();
-        } else if constexpr (plan_row_spans_waves(N)) {
+        if constexpr (plan_row_spans_waves(N)) {
             ++epoch;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // s_waitcnt lgkmcnt(0): my LDS reads/writes are done
             if (!mute) *mine = epoch;
@@ -564,21 +548,15 @@ __device__ __forceinline__ void pass1c_item(const DeviceBuffers &buf, const Casc
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
-    if constexpr (OW_P1_PIPELINE && N >= 1024) {  // loads a few texels at a time, the arithmetic in between (Pass1::pipelined_load_modulate); the table after it
-        Pass1<N>::template pipelined_load_modulate<AUX_H>(h, t, y, h0_c, om_c, time, [&] { Pass1<N>::wave_numbers(ik, t, ky, dkx); });
+    {
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
         issued();
-        stamp(1, h[0].x);
-    } else {
-        {
-            cplx a[P], b[P];
-            float om[P];
-            Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
-            issued();
-            Pass1<N>::modulate(h, a, b, om, time);
-        }
-        stamp(1, h[0].x);
-        Pass1<N>::wave_numbers(ik, t, ky, dkx);
+        Pass1<N>::modulate(h, a, b, om, time);
     }
+    stamp(1, h[0].x);
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     // the wave that holds texel row 0 (its first lane does; for N < 1024 it holds a few more rows, transformed along and
@@ -870,31 +848,20 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
     const float dkx = (2.0f * kPi) / cf.tile_x, dky = (2.0f * kPi) / cf.tile_y;
     const float ky = (float)(y - N / 2) * dky;
     float ik[P];
-    if constexpr (OW_P1_PIPELINE != 0) {  // loads a few texels at a time, the arithmetic in between (Pass1::pipelined_load_modulate); the table after it
+    {
         SplitTw<SG> twv;
         split_tw_fetch<SG>(twv, buf.tw_split, tau);
         wxi = buf.tw_split[SG::TW + xi];
-        Pass1<N>::template pipelined_load_modulate<AUX_H>(h, t, y, h0_c, om_c, time, [&] { Pass1<N>::wave_numbers(ik, t, ky, dkx); });
-        stamp(1, 0.0f);
+        cplx a[P], b[P];
+        float om[P];
+        Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
+        stamp(1, 0.0f);  // loads issued
         split_tw_commit<SG>(twv, tw_lds, tau);
-        stamp(2, h[15].x);
-        stamp(3, h[15].x);
-    } else {
-        {
-            SplitTw<SG> twv;
-            split_tw_fetch<SG>(twv, buf.tw_split, tau);
-            wxi = buf.tw_split[SG::TW + xi];
-            cplx a[P], b[P];
-            float om[P];
-            Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
-            stamp(1, 0.0f);  // loads issued
-            split_tw_commit<SG>(twv, tw_lds, tau);
-            stamp(2, a[15].x + om[15]);  // table committed (block barrier), own data arrived
-            Pass1<N>::modulate(h, a, b, om, time);
-        }
-        stamp(3, h[15].x);  // modulated
-        Pass1<N>::wave_numbers(ik, t, ky, dkx);
+        stamp(2, a[15].x + om[15]);  // table committed (block barrier), own data arrived
+        Pass1<N>::modulate(h, a, b, om, time);
     }
+    stamp(3, h[15].x);  // modulated
+    Pass1<N>::wave_numbers(ik, t, ky, dkx);
     if (t == 0) gstore8(pcol_c, Pass2<N>::pcol_index(y) * 8u, 0u, Pass1<N>::column_term(h, ik, t, dkx));
 
     // E[k] +- W_N^k O[k] for k = xi + T m, m = 2g and 2g + 1 (chunk g of four): staged values of row q
@@ -1058,46 +1025,24 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
     ws.at(0, 0.0f);
     __shared__ __attribute__((aligned(16))) cplx lds[PG::kLdsCplx];
     // g.n2 pass-2 blocks and g.n1 pass-1 blocks (multiples of 8, either may be 0): alternate in chunks of 8 while both last
-    // (OW_PAIR_SPLIT_CHUNK_LOG2: chunks of 2^k blocks, A/B builds of tools/kbench_2048pair; both counts are then multiples of 2^k)
-#ifndef OW_PAIR_SPLIT_CHUNK_LOG2
-#define OW_PAIR_SPLIT_CHUNK_LOG2 3
-#endif
     int index = blockIdx.x;
     bool first;  // is this a pass-1 block?
     {
-        constexpr int CL = OW_PAIR_SPLIT_CHUNK_LOG2;
-        const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> CL;
+        const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
         if (index < both) {
-            first = (chunk & 1) != OW_PAIR_P1_FIRST;
-            index = ((chunk >> 1) << CL) + (index & ((1 << CL) - 1));
+            first = chunk & 1;
+            index = ((chunk >> 1) << 3) + (index & 7);
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
         }
     }
-    if (OW_PAIR_P1_PRIO && first) __builtin_amdgcn_s_setprio(OW_PAIR_P1_PRIO);
-    if (OW_PAIR_P2_PRIO && !first) __builtin_amdgcn_s_setprio(OW_PAIR_P2_PRIO);
-#ifdef OW_PAIR_EXPERIMENT
-    // tools/kbench_2048pair only (the product never defines OW_PAIR_EXPERIMENT): de-phase the two kinds of block of the launch's FIRST wave generation
-    // (blocks below OW_PAIR_EXPERIMENT: the ones resident from the start, which otherwise all issue their load bursts at the same moment) by letting one kind
-    // sleep g.pad & 255 (pass 1) / (g.pad >> 8) & 255 (pass 2) times ~1024 clocks first; bit 16: every generation; bits 17-18: s_setprio of pass 1 / pass 2
-    {
-        const int naps = first ? (g.pad & 255) : ((g.pad >> 8) & 255);
-        if (naps > 0 && ((int)blockIdx.x < OW_PAIR_EXPERIMENT || (g.pad & (1 << 16))))
-            for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16);
-        if (first && (g.pad & (1 << 17))) __builtin_amdgcn_s_setprio(1);
-        if (!first && (g.pad & (1 << 18))) __builtin_amdgcn_s_setprio(1);
-    }
-#endif
     if (!first) {  // ---- pass 2 of 4 columns ----
         cplx *tw_lds = lds;
         cplx *rows_lds = lds + PG::kP2Tw;
         const int tau = threadIdx.x;
         int *sync_flags = reinterpret_cast<int *>(lds + PG::kP2Tw + PG::kCols * plan_region_cplx(N));
-#ifndef OW_P2_PAIR_BLOCK_BARRIER
-#define OW_P2_PAIR_BLOCK_BARRIER 0
-#endif
-        RowSync<N, OW_P2_PAIR_BLOCK_BARRIER != 0> rs;
+        RowSync<N> rs;
         rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
         rs.watch(buf.status, g.fault);
         init_row_sync<N>(sync_flags, PG::kCols);
@@ -1537,21 +1482,11 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
             return;
         }
     }
-    // which pass this block works for, and its index there: pass-2 blocks first -- or, g.interleave, alternating with the pass-1 blocks in chunks of 8
-    int bx = blockIdx.x;
-    bool second = bx < g.n2;
-    if (!PIPE && g.interleave) {
-        const int n1t = g.d1 * g.n1, both = 2 * (g.n2 < n1t ? g.n2 : n1t), chunk = bx >> 3;
-        if (bx < both) {
-            second = !(chunk & 1);
-            bx = ((chunk >> 1) << 3) + (bx & 7) + (second ? 0 : g.n2);
-        } else {
-            second = g.n2 > n1t;
-            bx = bx - both / 2 + (second ? 0 : g.n2);
-        }
-    }
-    if (!PIPE && second) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
-        const int item = bx;
+    // (pass-2 blocks first, then the pass-1 blocks.  Alternating the two kinds in chunks of 8, as the tick-pair kernels do, was measured for the
+    //  look-ahead's launches of one tick of pass 2 beside pass 1 of later ones -- and LOSES 3 - 9 %: 1024^2 x 4 on the reference's schedule 84.1 -> 87.0 us
+    //  per update, 1024^2 x 1 tick by tick 19.9 -> 21.8, 512^2 x 4 19.8 -> 21.5; profiles/EXPERIMENTS.md round 6)
+    if (!PIPE && (int)blockIdx.x < g.n2) {  // ---- pass 2 of d2 consecutive ticks of the same rows (block-uniform branch) ----
+        const int item = blockIdx.x;
         const int slot = item / (N / ROWS), row0 = (item % (N / ROWS)) * ROWS;
         const CascadeFrame cf = args.c[slot];  // (pass 2 does not use the time)
         fetch_arguments(buf, cf);
@@ -1573,7 +1508,7 @@ __global__ __launch_bounds__(plan_lp_threads(N), 4) void k_tick_group_c_lp(Devic
         return;
     }
     // ---- pass 1: tick j of the later group ----
-    const int b1 = bx - g.n2, j = b1 / g.n1, item = b1 % g.n1;
+    const int b1 = (int)blockIdx.x - g.n2, j = b1 / g.n1, item = b1 % g.n1;
     const int tau = threadIdx.x;
     const int sub = __builtin_amdgcn_readfirstlane(tau / SUB), tau_sub = tau % SUB;
     if (g.p1_compact) {  // (launch-uniform) Q 8-row items side by side, each doing all its layers (k_pass1c's body): no redundant modulation
@@ -1630,15 +1565,13 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     {
         const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
         if (index < both) {
-            first = (chunk & 1) != OW_PAIR_P1_FIRST;
+            first = chunk & 1;
             index = ((chunk >> 1) << 3) + (index & 7);
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
         }
     }
-    if (OW_PAIR_P1_PRIO && first) __builtin_amdgcn_s_setprio(OW_PAIR_P1_PRIO);
-    if (OW_PAIR_P2_PRIO && !first) __builtin_amdgcn_s_setprio(OW_PAIR_P2_PRIO);
     int slot, row0;
     if (!first) {
         constexpr int BPC = N / kWgRows;

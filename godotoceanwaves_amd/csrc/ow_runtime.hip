@@ -113,7 +113,6 @@ struct ow_context {
         double last_delta = 0.0;
         int run_streak = 0;          // how many runs like this one (same delta, same count) have preceded it without anything in between
     } ra;
-    int la_interleave = 1;      // the look-ahead's launches of both passes interleave their blocks (OW_DEBUG_LA_INTERLEAVE=0 in A/B builds)
     bool inside_run = false;    // ow_run is executing (its own ow_update_all calls are not "something in between")
     int pair_dir = 0;           // direction of the next block of the cascade-major pair stream (batches 0 .. B-1 or B-1 .. 0): alternates, across runs too
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
@@ -234,12 +233,10 @@ void plan_tick_groups(ow_context *c, uint32_t flags) {
     //   OW_DEBUG_TICK_GROUP_DEPTH        ticks per launch of the tick groups        OW_DEBUG_LOOKAHEAD_DEPTH  ticks of pass 1 computed ahead at most
     //   OW_DEBUG_PAIR_TICK_BLOCK         ticks a batch runs through before the stream of tick pairs moves on (1 = tick-major)
     //   OW_DEBUG_PAIR_TEXELS             batch size of the tick pairs in Mi texels
-    //   OW_DEBUG_LA_INTERLEAVE           0: the look-ahead's launches keep all pass-2 blocks in front of the pass-1 blocks
     if (const char *e = getenv("OW_DEBUG_RUN_DELTA_CHANGE_EVERY")) c->run_delta_period = std::max(0, std::min(1 << 20, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_TICK_GROUP_DEPTH")) c->group_depth_forced = std::max(0, std::min((int)ow::kMaxTickGroup, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_LOOKAHEAD_DEPTH")) c->ahead_depth = std::max(1, std::min((int)ow_context::Lookahead::kMaxAhead, atoi(e)));
     if (const char *e = getenv("OW_DEBUG_PAIR_TICK_BLOCK")) c->pair_tick_block = std::max(0, std::min(4096, atoi(e)));
-    if (const char *e = getenv("OW_DEBUG_LA_INTERLEAVE")) c->la_interleave = atoi(e) != 0;
     if (const char *e = getenv("OW_DEBUG_PAIR_TEXELS"))
         if (atol(e) >= 1 && atol(e) <= 64) c->pair_texels = (size_t)atol(e) << 20;
 #endif
@@ -720,7 +717,6 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
         // larger items (us per tick at four ticks ahead, lp | compact: 256^2 x 4 9.7 | 10.5, 512^2 x 1 10.2 | 11.2, 256^2 x 8 13.3 | 12.2,
         // 512^2 x 2 13.7 | 12.7, 512^2 x 4 23.9 | 19.7, 1024^2 x 1 23.0 | 19.7; profiles/r04_lookahead_depth.txt)
         ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)count * depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
-        ga.interleave = c->la_interleave;  // one tick of pass 2 beside pass 1 of later ones: the two kinds of block alternate (TickGroupArgs::interleave)
     }
     if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
     la.armed = la.queued > 0;
@@ -882,7 +878,6 @@ int prearm_launch(ow_context *c, const ow_cascade_params *records, int count, co
     ga.step1 = 1;
     ga.slots = 1;
     ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
-    ga.interleave = c->la_interleave;
     if (ow::launch_tick_group(c->n, args, ga, c->buf, c->stream) != hipSuccess) {
         (void)hipGetLastError();
         la.armed = false;

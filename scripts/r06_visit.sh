@@ -44,17 +44,6 @@ python scripts/rocprof_summary.py $O/scene_trace $O/scene_kernel_trace_144hz.txt
 rm -rf $O/scene_trace
 timeout 300 python scripts/scene_probe.py --hz 60 | grep "per update"
 fi
-if want sceneab; then   # the look-ahead's launches with their blocks interleaved (1) or pass 2 first (0): knobs build, alternating processes
-K=godotoceanwaves_amd/csrc/build/variants/knobs.so; : > $O/sceneab.txt
-for rep in 1 2 3; do for v in 0 1; do
-  echo "== interleave=$v (rep $rep)" >> $O/sceneab.txt
-  for hz in 144 60; do OW_DEBUG_LA_INTERLEAVE=$v OCEAN_WAVES_LIB=$PWD/$K timeout 300 python scripts/scene_probe.py --hz $hz 2>&1 | grep "per update" | cut -c1-110 >> $O/sceneab.txt; done
-  for cfg in "1024 4 reference" "512 4 reference" "256 4 reference" "1024 1 reference" "256 4 calls" "512 4 calls" "1024 1 calls"; do
-    echo -n "   $cfg: " >> $O/sceneab.txt; OW_DEBUG_LA_INTERLEAVE=$v OCEAN_WAVES_LIB=$PWD/$K timeout 300 python scripts/lookahead_ab.py --child $cfg 2>&1 | tail -1 >> $O/sceneab.txt
-  done
-done; done
-cat $O/sceneab.txt
-fi
 if want spectrum; then   # k_spectrum under a kernel trace, and its parity tests
 timeout 900 python -m pytest "tests/test_gpu_parity.py" -m gpu -q -k "spectrum or dirty or edges" --timeout 600 > $O/pytest_spectrum.log 2>&1; tail -3 $O/pytest_spectrum.log
 rm -rf $O/spec_trace

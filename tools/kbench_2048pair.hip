@@ -76,21 +76,6 @@ int main(int argc, char **argv) {
     printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
     printf("  one launch per pass (again)  : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
     printf("  k_tick_pair_c_split (again)  : %8.2f\n", time_it(pair, iters * C, s));
-#ifdef OW_PAIR_EXPERIMENT
-    {   // de-phasing / priority experiments of the pair kernel (round 6): PairArgs::pad carries the knobs (ow_frame_kernels.h, OW_PAIR_EXPERIMENT)
-        struct Knob { const char *name; int pad; };
-        const Knob knobs[] = {{"baseline", 0}, {"pass 1 sleeps 2 k clocks (first generation)", 2}, {"pass 1 sleeps 4 k", 4}, {"pass 1 sleeps 8 k", 8}, {"pass 1 sleeps 12 k", 12},
-                              {"pass 1 sleeps 16 k", 16}, {"pass 1 sleeps 24 k", 24}, {"pass 1 sleeps 32 k", 32}, {"pass 2 sleeps 4 k", 4 << 8}, {"pass 2 sleeps 8 k", 8 << 8},
-                              {"pass 2 sleeps 16 k", 16 << 8}, {"pass 2 sleeps 24 k", 24 << 8}, {"pass 1 sleeps 8 k, every generation", 8 | (1 << 16)},
-                              {"pass 2 sleeps 8 k, every generation", (8 << 8) | (1 << 16)}, {"pass 1 at priority 1", 1 << 17}, {"pass 2 at priority 1", 1 << 18},
-                              {"pass 1 sleeps 8 k + pass 2 at priority 1", 8 | (1 << 18)}, {"baseline (again)", 0}};
-        for (int rep = 0; rep < 2; ++rep)
-            for (const Knob &k : knobs) {
-                auto pairk = [&](int i) { PairArgs h = pair_args(i); h.pad = k.pad; hipLaunchKernelGGL((k_tick_pair_c_split<N, false>), dim3(g.n2 + g.n1), dim3(PT), 0, s, buf, h, (Stamp *)nullptr); };
-                printf("  pair stream, %-52s: %8.2f\n", k.name, time_it(pairk, iters * C, s));
-            }
-    }
-#endif
     uint32_t status = 0; CK(hipMemcpy(&status, buf.status, 4, hipMemcpyDeviceToHost));
     printf("  status word 0x%x\n", status);
 
