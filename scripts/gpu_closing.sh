@@ -1,10 +1,10 @@
 #!/bin/bash
 # closing state of a round: the GPU suite, the default bench line, the rocprofv3 kernel trace of the same command on the same box (and of the
 # 2048^2 x 4 configuration), PMC passes (separate runs, no tracing domains beside them), the sweep over north_star's grid, a slice of the fuzz.
-#   R=r05 bash scripts/gpu_closing.sh          PARTS="bench trace" R=r05 bash scripts/gpu_closing.sh   (a subset: tests bench trace trace2048 trace256 pmc sweep fuzz rehearsal hosts)
+#   R=r06 bash scripts/gpu_closing.sh          PARTS="bench trace" R=r06 bash scripts/gpu_closing.sh   (a subset: tests bench trace trace2048 trace256 pmc sweep fuzz margins overhead scene rehearsal hosts)
 cd "$GRAFT_REPO_ROOT" || exit 1
-R=${R:-r05}; O=gpurun_out/${R}_closing; mkdir -p $O; export TMPDIR=/tmp
-PARTS=${PARTS:-tests bench trace trace2048 trace256 pmc sweep fuzz rehearsal hosts}
+R=${R:-r06}; O=gpurun_out/${R}_closing; mkdir -p $O; export TMPDIR=/tmp
+PARTS=${PARTS:-tests bench trace trace2048 trace256 pmc fuzz margins overhead scene rehearsal hosts}   # (sweep: the whole grid rides in the bench line since round 6)
 want() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 if want tests; then
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
@@ -53,6 +53,17 @@ fi
 if want fuzz; then
 timeout 900 python scripts/fuzz_parity.py 30 501 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt
 timeout 900 python scripts/fuzz_schedule.py 12 501 > $O/fuzz_schedule.txt 2>&1; tail -3 $O/fuzz_schedule.txt
+fi
+if want margins; then
+timeout 900 python scripts/parity_margins.py > $O/parity_margins.txt 2>&1; grep "^==" $O/parity_margins.txt
+fi
+if want overhead; then
+timeout 900 python scripts/run_overhead.py 1024:8 2048:4 256:4 1024:4 > $O/run_overhead.txt 2>&1; grep "ow_run " $O/run_overhead.txt | cut -c1-120
+fi
+if want scene; then
+rm -rf $O/scene_trace
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/scene_trace" -o t -- python "$GRAFT_REPO_ROOT/scripts/scene_probe.py" --hz 144) > $O/scene_probe_144.log 2>&1
+python scripts/rocprof_summary.py $O/scene_trace $O/scene_kernel_trace_144hz.txt; grep "per update" $O/scene_probe_144.log; rm -rf $O/scene_trace
 fi
 if want rehearsal; then
 # the N > 1 rank code on the one GPU of the box (gloo, both ranks on GPU 0: control flow only, the numbers mean nothing)
