@@ -92,7 +92,10 @@ int main(int argc, char **argv) {
             if (s[i].displacement[1] > hmax) hmax = s[i].displacement[1];
             active += s[i].spray_active;
         }
-        printf("layers_handed_off=%d checksum=%016llx wave_height=[%.4f,%.4f] spray_active=%d\n", handed, (unsigned long long)sum, hmin, hmax, active);
+        uint64_t generated = 0, skipped = 0;   /* one spectrum per cascade, generated by its first ow_process; nothing regenerated since */
+        if (ow_spectrum_stats(ctx, &generated, &skipped) != OW_OK) goto fail;
+        printf("layers_handed_off=%d checksum=%016llx wave_height=[%.4f,%.4f] spray_active=%d spectra_generated=%llu spectra_skipped=%llu\n", handed, (unsigned long long)sum,
+               hmin, hmax, active, (unsigned long long)generated, (unsigned long long)skipped);
         if (!(hmax > hmin) || !isfinite(hmin) || !isfinite(hmax)) { fprintf(stderr, "flat or non-finite surface\n"); ow_destroy(ctx); return 1; }
     }
     ow_destroy(ctx);

@@ -77,6 +77,8 @@ def check_against_mirror(stdout, n, frames):
     lo, hi = out["wave_height"].strip("[]").split(",")
     assert abs(float(lo) - float(s["displacement"][:, 1].min())) < 1e-4 and abs(float(hi) - float(s["displacement"][:, 1].max())) < 1e-4
     assert int(out["spray_active"]) == int(s["spray_active"].sum())
+    if "spectra_generated" in out:   # (examples/c_consumer.c asks ow_spectrum_stats: one spectrum per cascade, none regenerated)
+        assert int(out["spectra_generated"]) == 3 and int(out["spectra_skipped"]) == 0
 
 
 @pytest.mark.gpu
@@ -85,3 +87,4 @@ def test_c_program_and_python_mirror_agree(tmp_path):
     r = subprocess.run([build(tmp_path), str(n), str(frames)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     check_against_mirror(r.stdout, n, frames)
+    assert "spectra_generated=3" in r.stdout

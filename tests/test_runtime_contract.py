@@ -233,3 +233,38 @@ def test_a_faulted_layer_stays_refused_until_that_layer_is_recomputed():
     gen.sync()
     gen.get_maps(0)
     gen.sample_surface([[1.0, 2.0]], scales)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,count", [(1024, 1), (512, 8), (256, 4)])
+def test_lazy_scratch_allocates_the_look_aheads_share_on_first_use_and_changes_nothing(n, count):
+    """OW_FLAG_LAZY_SCRATCH: ow_create allocates the scratch of ONE batch; what the look-ahead keeps in flight -- the pair kernel two batches,
+    the group kernel a ring of five groups -- is allocated by the first call that speculates.  Same calls, same bits as a context that allocated it up
+    front; and the lazy context really did start smaller (free device memory right after creation)."""
+    import torch
+    from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator
+    from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    a = WaveGenerator(); a.map_size, a.lazy_scratch = n, True; a.init_gpu(max(2, count))
+    free_lazy = torch.cuda.mem_get_info()[0]
+    b = WaveGenerator(); b.map_size = n; b.init_gpu(max(2, count))
+    free_eager = torch.cuda.mem_get_info()[0]
+    assert (free0 - free_lazy) < (free_lazy - free_eager)          # the eager context holds the look-ahead's scratch as well
+    pa = [WaveCascadeParameters(**cascade_preset(i)) for i in range(count)]
+    pb = [WaveCascadeParameters(**cascade_preset(i)) for i in range(count)]
+    for g, p in ((a, pa), (b, pb)):
+        for _ in range(5):
+            g.update_all(UPDATE_DELTA, p)                            # arms the look-ahead: the lazy context grows its scratch here
+        g.update(UPDATE_DELTA, p)
+        for _ in range(count):
+            g._process(0.0)
+        g.run(UPDATE_DELTA, p, 7)
+        g.run(UPDATE_DELTA, p, 7)
+        g.sync()
+    assert a.lookahead_stats() == b.lookahead_stats() and a.lookahead_stats()[0] > 0
+    for i in range(count):
+        da, na = a.get_maps(i)
+        db, nb = b.get_maps(i)
+        assert np.array_equal(da.view(np.uint16), db.view(np.uint16)) and np.array_equal(na.view(np.uint16), nb.view(np.uint16))
+    a.free(); b.free()
