@@ -140,8 +140,29 @@ def cpu_baseline(n, cascades, seconds):
     dt = time.perf_counter() - t0
     cores = O.lib(True).owo_num_threads()
     g.close()
-    return {"value": round(frames * cascades / dt, 3), "unit": "maps/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} ticks of {n}^2 x {cascades} cascades (oracle, OpenMP x{cores}, {dt:.1f} s)"}
+    out = {"value": round(frames * cascades / dt, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+           "sample": f"{frames} ticks of {n}^2 x {cascades} cascades (oracle, OpenMP x{cores}, {dt:.1f} s)"}
+    try:
+        out["reference_shaders"] = reference_shaders_baseline()
+    except Exception as e:  # (the prebuilt oracle/_ref is test infrastructure: its absence costs this sub-object, nothing else)
+        out["reference_shaders"] = {"error": str(e)[:160]}
+    return out
+
+
+def reference_shaders_baseline(n=256):
+    """The reference's OWN compute shaders (oracle/_ref: its .glsl sources compiled as C++ through oracle/glsl_shim.h, workgroups run one after the
+    other, barriers as fibres) on ONE host core: the steady-state dispatches of one update of one n^2 cascade -- spectrum_modulate, fft_compute,
+    transpose, fft_compute, fft_unpack (wave_generator.gd:73-85).  An interpreter-grade execution of GPU code, reported because north_star asks for the
+    reference's own compute path beside the port; a bounded sample (one 256^2 map: a 1024^2 map takes a minute this way)."""
+    from oracle import ref as R
+    from godotoceanwaves_amd.presets import UPDATE_DELTA, cascade_preset
+    if not R.available():
+        raise RuntimeError("oracle/_ref/libglsl_ref.so not built (needs the reference checkout at build time)")
+    c = R.RefCascade(n, cascade_preset(0))
+    c.update(UPDATE_DELTA)
+    return {"value": round(1.0 / c.last_steady_s, 4), "unit": "maps/s", "cores": 1, "kind": "reference",
+            "sample": f"1 update of one {n}^2 cascade through the reference's GLSL compiled as C++ (oracle/_ref, one thread, {c.last_steady_s:.1f} s; "
+                      f"x {(1024 // n) ** 2} texels at 1024^2)"}
 
 
 def measure_traffic(n, C, kernel, timeout_s=100, seamless=False):

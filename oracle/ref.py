@@ -8,6 +8,7 @@ git-ignored but travels with the working tree, and `available()` says whether it
 import ctypes as C
 import math
 import os
+import time
 
 import numpy as np
 
@@ -91,12 +92,14 @@ class RefCascade:
             L.ref_spectrum_compute(n, C.byref(pc), self.spectrum)
             self.dirty = False
         flat = self.fft.reshape(-1)
+        t0 = time.perf_counter()                                   # (bench.py's cpu_baseline.reference_shaders: the steady-state dispatches of one update)
         L.ref_spectrum_modulate(n, p["tile_length"][0], p["tile_length"][1], self.DEPTH, self.time, self.spectrum, flat)
         L.ref_fft_compute(n, self.butterfly, flat)
         L.ref_transpose(n, self.butterfly, flat)
         self.intermediate = self.fft[0].copy()                     # half 0 after the transpose
         L.ref_fft_compute(n, self.butterfly, flat)
         L.ref_fft_unpack(n, flat, p["whitecap"], grow, decay, self.displacement, self.normal)
+        self.last_steady_s = time.perf_counter() - t0
 
 
 def sample_surface(displacements, normals, map_scales, world_xz):

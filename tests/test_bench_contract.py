@@ -52,6 +52,8 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     uc = rf["update_all_calls"]
     assert uc["lookahead_hit_rate"] > 0.9 and 0.0 < uc["frac"] < 0.85 and uc["ms_per_step"] <= 1.05 * um["ms_per_step"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    rs = d["cpu_baseline"]["reference_shaders"]   # the reference's own GLSL on one host core (oracle/_ref, prebuilt): a bounded sample beside the port
+    assert "error" in rs or (rs["kind"] == "reference" and rs["cores"] == 1 and 0.0 < rs["value"] < d["cpu_baseline"]["value"])
     if not flags:  # measured by the run itself, and close to the design bytes (72.7 B/texel at the memory side against 72)
         assert rf["traffic_source"].startswith("measured by this run"), rf.get("traffic_measurement_failed")
         assert 0.9 < rf["traffic"] / rf["bytes_per_launch"] < 1.15 and rf["traffic_detail"]["full_launch_equivalents"] == 81   # (81 ticks, every launch a full pair: the seamless stream of round 5)
