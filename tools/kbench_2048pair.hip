@@ -26,6 +26,97 @@ float time_it(F f, int iters, hipStream_t s) {
     return ms / iters * 1e3f;
 }
 
+// Timeline of ONE launch of the pair kernel from its waves' stamps (wave 0 of every block): the cycle counters of the XCDs are not synchronised, so every
+// times come from s_memrealtime (one 100 MHz counter for the device).  Kinds: pass 2, pass 1 lower half (2 transforms), pass 1 upper half (3 transforms).
+static void timeline(const std::vector<Stamp> &h, int waves_per_block) {
+    constexpr int N = 2048;
+    unsigned long long r0 = ~0ull;
+    for (size_t i = 0; i < h.size(); i += waves_per_block) if (h[i].rt0) r0 = std::min(r0, h[i].rt0);
+    struct B { int kind; double st, en; unsigned cu; };
+    std::vector<B> bl;
+    for (size_t i = 0; i < h.size(); i += waves_per_block) {
+        const Stamp &x = h[i];
+        if (!x.t[0]) continue;
+        const int kind = x.t[15] == 100000ull ? 0 : ((int)(x.t[15] - 1000ull) >= N / 2 ? 2 : 1);
+        bl.push_back(B{kind, (double)(x.rt0 - r0) * 0.01, (double)(x.rt1 - r0) * 0.01, (x.xcc & 15) << 16 | (x.pad & 0xff00)});   // us
+    }
+    const char *kn[3] = {"pass 2", "pass 1, 2 transforms", "pass 1, 3 transforms"};
+    auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (v.size() - 1))]; };
+    double end_max = 0; for (auto &b : bl) end_max = std::max(end_max, b.en);
+    printf("timeline of one launch (%zu blocks, us since the launch's first wave by the device's 100 MHz real-time counter; last block ends at %.2f):\n", bl.size(), end_max);
+    for (int gen = 0; gen < 2; ++gen)
+        for (int k = 0; k < 3; ++k) {
+            std::vector<double> st, en, life;
+            for (auto &b : bl) if (b.kind == k && (b.st < 5.0) == (gen == 0)) { st.push_back(b.st); en.push_back(b.en); life.push_back(b.en - b.st); }
+            if (st.empty()) continue;
+            printf("  %s blocks of %-22s: %4zu  start p10/p50/p90 %6.2f %6.2f %6.2f   end p10/p50/p90/max %6.2f %6.2f %6.2f %6.2f   life p50 %6.2f\n", gen ? "later" : "first", kn[k], st.size(),
+                   pct(st, .1), pct(st, .5), pct(st, .9), pct(en, .1), pct(en, .5), pct(en, .9), pct(en, 1.0), pct(life, .5));
+        }
+    const double bin = 2.0; const int nb = (int)(end_max / bin) + 1;
+    printf("  blocks resident per %.0f-us bin (pass 2 / pass 1 short / pass 1 long):\n   ", bin);
+    for (int i = 0; i < nb; ++i) {
+        double a[3] = {0, 0, 0};
+        for (auto &b : bl) { const double lo = std::max(b.st, i * bin), hi = std::min(b.en, (i + 1) * bin); if (hi > lo) a[b.kind] += (hi - lo) / bin; }
+        printf(" %3.0f/%3.0f/%3.0f", a[0], a[1], a[2]);
+    }
+    printf("\n");
+    // which kinds shared a CU in the first generation
+    int both = 0, p2p2 = 0, p1p1 = 0, single = 0;
+    std::vector<std::pair<unsigned, int>> first;
+    for (auto &b : bl) if (b.st < 5.0) first.push_back({b.cu, b.kind ? 1 : 0});
+    std::sort(first.begin(), first.end());
+    for (size_t i = 0; i < first.size();) {
+        size_t j = i; int n1 = 0, n2 = 0;
+        while (j < first.size() && first[j].first == first[i].first) { (first[j].second ? n1 : n2)++; ++j; }
+        if (n1 && n2) ++both; else if (n2 >= 2) ++p2p2; else if (n1 >= 2) ++p1p1; else ++single;
+        i = j;
+    }
+    {   // who the stragglers are: life of first-generation blocks by the kinds that shared their CU, and ends by XCD
+        std::vector<std::pair<unsigned, size_t>> byc;
+        for (size_t i = 0; i < bl.size(); ++i) if (bl[i].st < 5.0) byc.push_back({bl[i].cu, i});
+        std::sort(byc.begin(), byc.end());
+        std::vector<double> combo[6];  // 0: P2 beside P2, 1: S beside S, 2: S beside L, 3: L beside S, 4: L beside L, 5: other
+        for (size_t i = 0; i + 1 < byc.size(); i += 2) {
+            if (byc[i].first != byc[i + 1].first) { --i; continue; }
+            const B &a = bl[byc[i].second], &c = bl[byc[i + 1].second];
+            auto cls = [](int k, int o) { return k == 0 && o == 0 ? 0 : k == 1 && o == 1 ? 1 : k == 1 && o == 2 ? 2 : k == 2 && o == 1 ? 3 : k == 2 && o == 2 ? 4 : 5; };
+            combo[cls(a.kind, c.kind)].push_back(a.en - a.st);
+            combo[cls(c.kind, a.kind)].push_back(c.en - c.st);
+        }
+        const char *cn[6] = {"pass 2 beside pass 2", "short beside short", "short beside long", "long beside short", "long beside long", "other"};
+        for (int k = 0; k < 6; ++k) if (!combo[k].empty()) printf("  first generation, %-22s: %4zu blocks, life p10/p50/p90/max %6.2f %6.2f %6.2f %6.2f\n", cn[k], combo[k].size(), pct(combo[k], .1), pct(combo[k], .5), pct(combo[k], .9), pct(combo[k], 1.0));
+        for (int x = 0; x < 8; ++x) {
+            std::vector<double> e1, e2;
+            for (auto &b : bl) if ((int)(b.cu >> 16) == x) (b.st < 5.0 ? e1 : e2).push_back(b.en);
+            printf("  XCD %d: first generation ends p50/p90/max %6.2f %6.2f %6.2f   later blocks end p50/p90/max %6.2f %6.2f %6.2f\n", x, pct(e1, .5), pct(e1, .9), pct(e1, 1.0), pct(e2, .5), pct(e2, .9), pct(e2, 1.0));
+        }
+    }
+    {   // inside a block: how far apart its waves end; between blocks: from the end of a CU's n-th block (its LAST wave) to the start of the CU's (n + 2)-th (the hand-over of a slot)
+        std::vector<double> skew, gap;
+        struct E { unsigned cu; double st, en_first, en_last; };
+        std::vector<E> ev;
+        for (size_t i = 0; i < h.size(); i += waves_per_block) {
+            if (!h[i].rt0) continue;
+            unsigned long long e0 = ~0ull, e1 = 0, s0 = ~0ull;
+            for (int w = 0; w < waves_per_block; ++w) { e0 = std::min(e0, h[i + w].rt1); e1 = std::max(e1, h[i + w].rt1); s0 = std::min(s0, h[i + w].rt0); }
+            skew.push_back((double)(e1 - e0) * 0.01);
+            ev.push_back(E{(h[i].xcc & 15) << 16 | (h[i].pad & 0xff00), (double)(s0 - r0) * 0.01, (double)(e0 - r0) * 0.01, (double)(e1 - r0) * 0.01});
+        }
+        std::sort(ev.begin(), ev.end(), [](const E &a, const E &b) { return a.cu != b.cu ? a.cu < b.cu : a.st < b.st; });
+        for (size_t i = 0; i < ev.size();) {
+            size_t j = i; while (j < ev.size() && ev[j].cu == ev[i].cu) ++j;
+            if (j - i == 4) {  // two first-generation blocks, two later ones: the later ones take the slots in the order the first ones free them
+                std::vector<double> ends = {ev[i].en_last, ev[i + 1].en_last}; std::sort(ends.begin(), ends.end());
+                gap.push_back(ev[i + 2].st - ends[0]); gap.push_back(ev[i + 3].st - ends[1]);
+            }
+            i = j;
+        }
+        printf("  inside a block, last wave's end - first wave's end: p50/p90/max %5.2f %5.2f %5.2f us;  slot hand-over (a block's last wave ends -> the next block's first wave starts): p10/p50/p90 %5.2f %5.2f %5.2f us (%zu)\n",
+               pct(skew, .5), pct(skew, .9), pct(skew, 1.0), pct(gap, .1), pct(gap, .5), pct(gap, .9), gap.size());
+    }
+    printf("  first generation, per CU (xcc, se, sh, cu of HW_ID): one block of each pass on %d CUs, two pass-2 blocks on %d, two pass-1 blocks on %d, a single block on %d\n", both, p2p2, p1p1, single);
+}
+
 int main(int argc, char **argv) {
     constexpr int N = 2048;
     const int C = std::min(8, argc > 1 ? atoi(argv[1]) : 4), iters = argc > 2 ? atoi(argv[2]) : 40;
@@ -76,6 +167,28 @@ int main(int argc, char **argv) {
     printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
     printf("  one launch per pass (again)  : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
     printf("  k_tick_pair_c_split (again)  : %8.2f\n", time_it(pair, iters * C, s));
+    auto pair2 = [&](int i) { hipLaunchKernelGGL((k_tick_pair2_c_split<N, false>), dim3((g.n2 + g.n1) / 2), dim3(PT), 0, s, buf, pair_args(i), (Stamp *)nullptr); };
+    auto pair21 = [&](int i) { hipLaunchKernelGGL((k_tick_pair2_c_split<N, false, false, 1>), dim3(g.n2 + g.n1), dim3(PT), 0, s, buf, pair_args(i), (Stamp *)nullptr); };
+    for (int r = 0; r < 3; ++r) {
+        printf("  k_tick_pair2_c_split<1 item> : %8.2f   (the two-item kernel's code, one item per block)\n", time_it(pair21, iters * C, s));
+        printf("  k_tick_pair2_c_split stream  : %8.2f   (two items per block)\n", time_it(pair2, iters * C, s));
+        printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
+    }
+    {   // same bits?  seven launches of either kernel from the same state
+        auto snapshot = [&](auto launch) {
+            CK(hipMemset(buf.foam, 0, L * pl * 2)); CK(hipMemset(buf.norm, 0, L * pl * 8)); CK(hipMemset(buf.disp, 0, L * pl * 8)); CK(hipMemset(buf.T, 0, 2 * pl * 32));
+            CK(hipMemset(buf.pcol, 0, 2 * (size_t)N * 8)); CK(hipMemset(buf.rrow, 0, 2 * (size_t)N * 32));
+            for (int i = 0; i < 7; ++i) launch(i);
+            CK(hipStreamSynchronize(s));
+            std::vector<unsigned char> v(L * pl * 18 + 2 * pl * 32);
+            CK(hipMemcpy(v.data(), buf.disp, L * pl * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data() + L * pl * 8, buf.norm, L * pl * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(v.data() + L * pl * 16, buf.foam, L * pl * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data() + L * pl * 18, buf.T, 2 * pl * 32, hipMemcpyDeviceToHost));
+            return v;
+        };
+        const auto va = snapshot(pair), vb = snapshot(pair2);
+        size_t diff = 0, nz = 0; for (size_t i = 0; i < va.size(); ++i) { diff += va[i] != vb[i]; nz += va[i] != 0; }
+        printf("  two items per block against one: %zu of %zu bytes differ (%zu non-zero)\n", diff, va.size(), nz);
+    }
     uint32_t status = 0; CK(hipMemcpy(&status, buf.status, 4, hipMemcpyDeviceToHost));
     printf("  status word 0x%x\n", status);
 
@@ -121,6 +234,35 @@ int main(int argc, char **argv) {
         double s1 = 0; int c1 = 0;
         for (auto &x : h) if (x.t[15] >= 1000ull && x.t[15] < 1000ull + N) { s1 += (double)(x.t[0] - t0); ++c1; }
         if (c1) printf("  pass-1 waves (%d): average start %.0f clocks into the launch\n", c1, s1 / c1);
+        timeline(h, W2);
+    }
+    {
+        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL((k_tick_pair2_c_split<N, false, true>), dim3((g.n2 + g.n1) / 2), dim3(PT), 0, s, buf, pair_args(i), st);
+        CK(hipStreamSynchronize(s));
+        std::vector<Stamp> h((size_t)(g.n2 + g.n1) / 2 * W2); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        unsigned long long r0 = ~0ull; for (auto &x : h) if (x.rt0) r0 = std::min(r0, x.rt0);
+        std::vector<double> e2, e1, m2; for (size_t i = 0; i < h.size(); i += W2) { (h[i].t[15] == 100000ull ? e2 : e1).push_back((double)(h[i].rt1 - r0) * 0.01); }
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (v.size() - 1))]; };
+        {
+            std::vector<double> l1, l2, st2;
+            for (size_t i = 0; i < h.size(); i += W2) {
+                const Stamp &x = h[i];
+                if (x.t[15] != 100000ull || x.t[14] == x.t[0]) continue;
+                const double us_per_clk = (double)(x.rt1 - x.rt0) * 0.01 / (double)(x.t[14] - x.t[0]);
+                l1.push_back((double)(x.t[1] - x.t[0]) * us_per_clk); l2.push_back((double)(x.t[14] - x.t[1]) * us_per_clk);
+            }
+            printf("  pass-2 blocks: first item p10/p50/p90 %6.2f %6.2f %6.2f us, second item %6.2f %6.2f %6.2f us\n", pct(l1, .1), pct(l1, .5), pct(l1, .9), pct(l2, .1), pct(l2, .5), pct(l2, .9));
+            std::vector<double> a1, a2;
+            for (size_t i = 0; i < h.size(); i += W2) {
+                const Stamp &x = h[i];
+                if (x.t[15] == 100000ull || x.t[14] == x.t[0]) continue;
+                const double us_per_clk = (double)(x.rt1 - x.rt0) * 0.01 / (double)(x.t[14] - x.t[0]);
+                a1.push_back((double)(x.t[1] - x.t[0]) * us_per_clk); a2.push_back((double)(x.t[14] - x.t[1]) * us_per_clk);
+            }
+            printf("  pass-1 blocks: until the second item's loads are out p10/p50/p90 %6.2f %6.2f %6.2f us, from there to the end %6.2f %6.2f %6.2f us\n", pct(a1, .1), pct(a1, .5), pct(a1, .9), pct(a2, .1), pct(a2, .5), pct(a2, .9));
+        }
+        printf("k_tick_pair2_c_split (two items per block): blocks end (us since the first wave) pass 2 p10/p50/p90/max %6.2f %6.2f %6.2f %6.2f   pass 1 %6.2f %6.2f %6.2f %6.2f\n",
+               pct(e2, .1), pct(e2, .5), pct(e2, .9), pct(e2, 1.0), pct(e1, .1), pct(e1, .5), pct(e1, .9), pct(e1, 1.0));
     }
     return 0;
 }
