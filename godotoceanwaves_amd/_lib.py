@@ -19,6 +19,7 @@ OW_FLAG_RUN_AS_REFERENCE_SCHEDULE = 64
 OW_FLAG_GROUP_P1_LP, OW_FLAG_GROUP_P1_COMPACT, OW_FLAG_GROUP_P2_PLAIN, OW_FLAG_GROUP_P2_PIPE = 0x100, 0x200, 0x400, 0x800
 OW_FLAG_ALWAYS_REGENERATE_SPECTRUM = 0x1000
 OW_FLAG_LAZY_SCRATCH = 0x2000
+OW_FLAG_SINGLE_STREAM = 0x4000
 OW_OK, OW_ERR_INVALID, OW_ERR_NO_DEVICE, OW_ERR_HIP, OW_ERR_NOMEM, OW_ERR_STATE = range(6)
 
 
@@ -84,6 +85,7 @@ SIGNATURES = {
     "ow_run": (C.c_int, [C.c_void_p, C.c_double, _P(ow_cascade_params), C.c_int32, C.c_int32]),
     "ow_lookahead_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
     "ow_spectrum_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
+    "ow_chain_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "ow_cascades_remaining": (C.c_int32, [C.c_void_p]),
     "ow_last_kernel_family": (C.c_int32, [C.c_void_p]),
     "ow_last_batch_cascades": (C.c_int32, [C.c_void_p]),

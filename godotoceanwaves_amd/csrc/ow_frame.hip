@@ -102,10 +102,23 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
 }
 
 // ---- tick pairs on the compact family (k_tick_pair_c): k_pass2c's blocks of one batch, k_pass1c's of the next, in one launch ----
+constexpr int kChainSlots = 4;  // a side of a tick-pair launch that two chains share: four cascades (two each)
+bool tick_pair_splits(int n, const TickGroupArgs &g) {
+    return n == 1024 && g.pair_compact && (g.slots2 == kChainSlots || g.slots2 == 0) && (g.slots1 == kChainSlots || g.slots1 == 0) && g.slots2 + g.slots1 > 0;
+}
 template <int N, bool F32>
-static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
+static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt, hipStream_t side = nullptr) {
     if (g.slots2 < 0 || g.slots1 < 0 || g.first2 < 0 || g.first1 < 0 || g.first2 + g.slots2 > kMaxCascades || g.first1 + g.slots1 > kMaxCascades)
         return hipErrorInvalidValue;
+    if (side && !lt.start && tick_pair_splits(N, g)) {  // two chains: launch slots [first, first + 2) of both sides on s, [first + 2, first + 4) on side
+        TickGroupArgs h = g;
+        h.slots2 = g.slots2 / 2, h.slots1 = g.slots1 / 2;
+        const hipError_t e = launch_pair_n<N, F32>(args, h, buf, s, lt);
+        if (e != hipSuccess) return e;
+        h.first2 = g.first2 + h.slots2, h.first1 = g.first1 + h.slots1;
+        h.tbase2[0] = g.tbase2[0] + h.slots2, h.tbase1[0] = g.tbase1[0] + h.slots1;  // (scratch slot = tbase + index inside the batch)
+        return launch_pair_n<N, F32>(args, h, buf, side, lt);
+    }
     constexpr int per2 = plan_split(N) ? N / PairSplitGeo<N>::kCols : N / kWgRows;  // blocks per cascade: 4 columns / 4 rows at 2048 (8-wave blocks of
     constexpr int per1 = plan_split(N) ? N / 4 : N / kWgRows;                       // both kinds), 8 columns / 8 rows below
     g.n2 = g.slots2 * per2;
@@ -125,9 +138,9 @@ static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const De
 }
 // ---- tick groups (k_tick_group_c_lp): pass 2 of d2 ticks and pass 1 of d1 later ticks in one launch ----
 template <int N, bool F32>
-static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
+static hipError_t launch_group_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt, hipStream_t side) {
     using TP = TickPlan<N>;
-    if (g.pair_compact) return launch_pair_n<N, F32>(args, g, buf, s, lt);
+    if (g.pair_compact) return launch_pair_n<N, F32>(args, g, buf, s, lt, side);
     if (plan_lp_rows(N) < 2) g.p2_pipe = 0;
     if (g.slots < 1 || g.first1 < 0 || g.step1 < 0 || g.first1 + (g.d1 > 0 ? g.d1 - 1 : 0) * g.step1 + g.slots > kMaxCascades) return hipErrorInvalidValue;
     g.n2 = g.d2 > 0 ? (g.p2_pipe ? TP::items_2_pipe(g.slots) : TP::items_2(g.slots)) : 0;
@@ -143,10 +156,10 @@ bool tick_pairs_supported(int n) { return tick_groups_supported(n) || n == 2048;
 int tick_group_pipe_blocks(int n, int slots) {
     return n == 256 ? TickPlan<256>::items_2_pipe(slots) : n == 512 ? TickPlan<512>::items_2_pipe(slots) : n == 1024 ? TickPlan<1024>::items_2_pipe(slots) : 0;
 }
-hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt) {
+hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt, hipStream_t side) {
     if (g.d2 < 0 || g.d1 < 0 || g.d2 > kMaxTickGroup || g.d1 > kMaxTickGroup) return hipErrorInvalidValue;
 #define OW_GROUP(NN) \
-    case NN: return buf.f32 ? launch_group_n<NN, true>(args, g, buf, s, lt) : launch_group_n<NN, false>(args, g, buf, s, lt);
+    case NN: return buf.f32 ? launch_group_n<NN, true>(args, g, buf, s, lt, side) : launch_group_n<NN, false>(args, g, buf, s, lt, side);
     switch (n) {
         OW_GROUP(256)
         OW_GROUP(512)

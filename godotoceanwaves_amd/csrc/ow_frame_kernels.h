@@ -26,18 +26,6 @@ namespace ow {
 
 // VAR bits (kbench only; the product instantiates VAR = 0):
 //   1 = no global loads (synthetic data), 2 = no stores, 4 = no FFT, 8 = per-wave timestamps
-#ifndef OW_PAIR_FLIP
-#define OW_PAIR_FLIP 0
-#endif
-#ifndef OW_PAIR_ORDER
-#define OW_PAIR_ORDER 0
-#endif
-#ifndef OW_PAIR2_TABLE_FIRST
-#define OW_PAIR2_TABLE_FIRST 0
-#endif
-#ifndef OW_PAIR2_BARRIER
-#define OW_PAIR2_BARRIER 0
-#endif
 struct Stamp {
     unsigned long long t[16];
     unsigned xcc, pad;
@@ -840,9 +828,7 @@ __device__ __forceinline__ void split_tw_commit(const SplitTw<SG> &p, cplx *tw_l
 // (tools/kbench_2048pair).
 template <int N, int ROWS, int AUX_T, int AUX_H, class Stamper>
 __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, const CascadeFrame &cf, float time, int tslot, int row0, int fault, cplx *tw_lds,
-                                                  cplx *rows_lds, int *sync_flags, int tau, Stamper stamp, int table_resident = 0) {
-    // (table_resident, block-uniform: the block has run an item before -- the N/2-plan table is in LDS already, and what takes the place of its commit is the
-    //  block barrier that says every wave has read the last staged rows of the previous item out of the regions)
+                                                  cplx *rows_lds, int *sync_flags, int tau, Stamper stamp) {
     using SG = SplitGeo<N, ROWS>;
     constexpr int H = SG::H, TH = SG::TH, P = kP, LC = Pass1<N>::kCompactLayers, T = plan_T(N);
     const int wv = __builtin_amdgcn_readfirstlane(tau / 64), rw = wv >> 1, w = wv & 1;  // row inside the item, parity
@@ -871,14 +857,13 @@ __device__ __forceinline__ void pass1c_split_item(const DeviceBuffers &buf, cons
     float ik[P];
     {
         SplitTw<SG> twv;
-        if (!table_resident) split_tw_fetch<SG>(twv, buf.tw_split, tau);
+        split_tw_fetch<SG>(twv, buf.tw_split, tau);
         wxi = buf.tw_split[SG::TW + xi];
         cplx a[P], b[P];
         float om[P];
         Pass1<N>::template load_raw<AUX_H>(a, b, om, t, y, h0_c, om_c);
         stamp(1, 0.0f);  // loads issued
-        if (!table_resident) split_tw_commit<SG>(twv, tw_lds, tau);
-        else lds_barrier();
+        split_tw_commit<SG>(twv, tw_lds, tau);
         stamp(2, a[15].x + om[15]);  // table committed (block barrier), own data arrived
         Pass1<N>::modulate(h, a, b, om, time);
     }
@@ -1052,29 +1037,8 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
     {
         const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
         if (index < both) {
-#if OW_PAIR_FLIP
-            // (experiment) the kinds still alternate chunk by chunk, but the order flips every OW_PAIR_FLIP chunks: an XCD hands its blocks to its 32 CUs in
-            // turn, so the two blocks a CU holds are OW_PAIR_FLIP positions of the XCD's sequence apart -- with the plain alternation always of the same kind
-            first = (chunk + chunk / OW_PAIR_FLIP) & 1;
-            index = (((chunk / OW_PAIR_FLIP) * (OW_PAIR_FLIP / 2) + ((chunk % OW_PAIR_FLIP) >> 1)) << 3) + (index & 7);
-#elif OW_PAIR_ORDER == 1
-            // (experiment, n2 == n1 == 512) second half of the launch: all pass-2 chunks, then the long pass-1 chunks, then the short ones -- the slots that free last get the shortest blocks
-            if (chunk < 64) { first = chunk & 1; index = ((chunk >> 1) << 3) + (index & 7); }
-            else if (chunk < 96) { first = false; index = ((32 + (chunk - 64)) << 3) + (index & 7); }
-            else { const int k = (chunk - 96) & 15, c = 32 + (k >> 2) * 8 + (chunk < 112 ? 4 : 0) + (k & 3); first = true; index = (c << 3) + (index & 7); }
-#elif OW_PAIR_ORDER == 2
-            // (experiment) longest first: pass 2 beside the long pass-1 chunks in the first half of the launch, beside the short ones in the second
-            { const int k = (chunk & 63) >> 1; first = chunk & 1; index = ((first ? (k >> 2) * 8 + (chunk < 64 ? 4 : 0) + (k & 3) : chunk >> 1) << 3) + (index & 7); }
-#elif OW_PAIR_ORDER == 3
-            // (experiment) second half of the launch: long pass-1 chunks first, then pass 2, then the short ones
-            if (chunk < 64) { first = chunk & 1; index = ((chunk >> 1) << 3) + (index & 7); }
-            else if (chunk < 80) { const int k = chunk - 64; first = true; index = ((32 + (k >> 2) * 8 + 4 + (k & 3)) << 3) + (index & 7); }
-            else if (chunk < 112) { first = false; index = ((32 + (chunk - 80)) << 3) + (index & 7); }
-            else { const int k = chunk - 112; first = true; index = ((32 + (k >> 2) * 8 + (k & 3)) << 3) + (index & 7); }
-#else
             first = chunk & 1;
             index = ((chunk >> 1) << 3) + (index & 7);
-#endif
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;
@@ -1109,80 +1073,6 @@ __global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair_c_
     pass1c_split_item<N, 4, kAuxDefault, kAuxDefault>(buf, cf, g.time1[launch_slot], g.tbase1 + slot, row0, g.fault, lds, lds + SG::TW,
                                                       reinterpret_cast<int *>(lds + SG::kLdsCplx), (int)threadIdx.x, [&](int k, float keep) { ws.at(k, keep); });
     ws.write(stamps, PG::kThreads / 64, 1000ull + (unsigned long long)row0);
-}
-
-// TWO ITEMS PER BLOCK (round 6).  The launch above is exactly two generations of blocks (1024 blocks on 512 block slots), and its timeline
-// (tools/kbench_2048pair, s_memrealtime stamps) says where a tenth of it goes: a slot is handed from a block to the next only when the block's LAST wave
-// has ended (the waves of a block end 1.6 us apart at the median, 4 us at the 90th percentile), the hand-over itself takes 1 us, and the new block fetches its
-// arguments and its table again.  Here the launch is 512 blocks that stay: each does the item its slot would have got first and then the one it would have got
-// second -- a wave goes on to its next item's loads as soon as IT is done (pass 2: nothing but the wave pair's own rendezvous lies between two items; pass 1:
-// one block barrier, behind the loads), the table is fetched once, nothing is torn down and set up in between.  Same item bodies, same results.
-// Pass-1 blocks take a lower-half item (two transforms) and an upper-half item (three), in either order, so that every block carries the same work
-// and mirror groups still meet in time on their XCD (the first items are the first generation of the launch above; the second item is the mirror KIND of the
-// one the slot's index would have had).  Needs n2 == n1, both multiples of 16 (2048^2: always, one cascade per batch).
-template <int N, bool F32, bool STAMPS = false, int ITEMS = 2>
-__global__ __launch_bounds__((PairSplitGeo<N>::kThreads), 4) void k_tick_pair2_c_split(DeviceBuffers buf, PairArgs g, Stamp *stamps = nullptr) {
-    static_assert(plan_split(N), "rows that span two waves (N = 2048)");
-    using PG = PairSplitGeo<N>;
-    using SG = typename PG::SG;
-    WaveStamps<STAMPS> ws;
-    ws.at(0, 0.0f);
-    __shared__ __attribute__((aligned(16))) cplx lds[PG::kLdsCplx];
-    const int chunk = (int)blockIdx.x >> 3, q = ((chunk >> 1) << 3) + ((int)blockIdx.x & 7), half = ITEMS == 2 ? g.n2 >> 1 : 0;   // (ITEMS == 1: this code as a one-item kernel, for A/B)
-    if (!(chunk & 1)) {  // ---- pass 2 of 4 columns, twice ----
-        cplx *tw_lds = lds;
-        cplx *rows_lds = lds + PG::kP2Tw;
-        const int tau = threadIdx.x;
-        int *sync_flags = reinterpret_cast<int *>(lds + PG::kP2Tw + PG::kCols * plan_region_cplx(N));
-        RowSync<N> rs;
-        rs.attach(sync_flags, tau / plan_T(N), (tau / 64) & 1);
-        rs.watch(buf.status, g.fault);
-        init_row_sync<N>(sync_flags, PG::kCols);
-        constexpr int BPC = N / PG::kCols;
-#if OW_PAIR2_TABLE_FIRST
-        TablePrefetch<PG::kP2Tw, PG::kThreads> twp0;
-        twp0.fetch(p2c_table<N>(buf));
-#endif
-#pragma clang loop unroll(disable)
-        for (int it = 0; it < ITEMS; ++it) {
-#if OW_PAIR2_BARRIER
-            if (it) lds_barrier();
-#endif
-            const int index = q + it * half;
-            const int slot = index / BPC, row0 = (index % BPC) * PG::kCols;
-            const CascadeFrame cf = pair_frame(g, g.first2 + slot);
-            if (it == 0) fetch_arguments(buf, cf);
-            uint32_t foam_pk[kP / 2];
-            pass2c_item<N, F32, kAuxDefault, kAuxNT>(buf, cf, g.tbase2 + slot, row0, opaque(tau), tw_lds, rows_lds, rs, [&] {
-                if (it == 0) {  // (asked for behind the item's own loads and not before them: prefetched values would stay in registers through the whole loop)
-#if OW_PAIR2_TABLE_FIRST
-                    twp0.commit(tw_lds);
-#else
-                    TablePrefetch<PG::kP2Tw, PG::kThreads> twp;
-                    twp.fetch(p2c_table<N>(buf));
-                    twp.commit(tw_lds);
-#endif
-                }
-            }, foam_pk);
-            if (it == 0) ws.at(1, 0.0f);
-        }
-        ws.write(stamps, PG::kThreads / 64, 100000ull);
-        return;
-    }
-    // ---- pass 1 of 4 rows, twice: index q of the first half of the items, then the mirror kind of index q + half ----
-#pragma clang loop unroll(disable)
-    for (int it = 0; it < ITEMS; ++it) {
-        const int index = it == 0 ? q : ((q + half) ^ 32);  // (bit 5 of a split item's index: lower / upper half of the rows, p1_index_to_rows<N, 2>)
-        int slot, row0;
-        p1_index_to_rows<N, kWgRows / 4>(index, slot, row0);
-        const int launch_slot = g.first1 + slot;
-        const CascadeFrame cf = pair_frame(g, launch_slot);
-        if (it == 0) fetch_arguments(buf, cf);
-        pass1c_split_item<N, 4, kAuxDefault, kAuxDefault>(buf, cf, g.time1[launch_slot], g.tbase1 + slot, row0, g.fault, lds, lds + SG::TW,
-                                                          reinterpret_cast<int *>(lds + SG::kLdsCplx), opaque((int)threadIdx.x), [&](int k, float keep) { if (it == 1) ws.at(k, keep); }, it);
-        if (it == 0) ws.at(15, 0.0f);
-    }
-    ws.write(stamps, PG::kThreads / 64, 1000ull);
 }
 
 // ===================================================================================================
@@ -1682,15 +1572,8 @@ __global__ __launch_bounds__(plan_wg_threads(N), 4) void k_tick_pair_c(DeviceBuf
     {
         const int both = 2 * (g.n2 < g.n1 ? g.n2 : g.n1), chunk = index >> 3;
         if (index < both) {
-#if OW_PAIR_FLIP
-            // (experiment) the kinds still alternate chunk by chunk, but the order flips every OW_PAIR_FLIP chunks: an XCD hands its blocks to its 32 CUs in
-            // turn, so the two blocks a CU holds are OW_PAIR_FLIP positions of the XCD's sequence apart -- with the plain alternation always of the same kind
-            first = (chunk + chunk / OW_PAIR_FLIP) & 1;
-            index = (((chunk / OW_PAIR_FLIP) * (OW_PAIR_FLIP / 2) + ((chunk % OW_PAIR_FLIP) >> 1)) << 3) + (index & 7);
-#else
             first = chunk & 1;
             index = ((chunk >> 1) << 3) + (index & 7);
-#endif
         } else {
             first = g.n2 < g.n1;
             index -= both / 2;

@@ -63,6 +63,14 @@ bool tick_groups_supported(int n);
 bool tick_pairs_supported(int n);
 int tick_group_pipe_blocks(int n, int slots);  // pass-2 blocks of the pipelined form (0: not available at this map size)
 hipError_t launch_tick_group(int n, const FrameArgs &args, const TickGroupArgs &g, const DeviceBuffers &buf, hipStream_t s,
-                             const LaunchTiming &lt = LaunchTiming{});
+                             const LaunchTiming &lt = LaunchTiming{}, hipStream_t side = nullptr);
+// TWO CHAINS (round 6).  A tick-pair launch of four 1024^2 cascades on either side is exactly two generations of blocks, and the kernel boundary between
+// two such launches costs a tenth of them: the chip drains (the last 8 us run below half occupancy) and fills again.  Cascades are independent, so the
+// launch can go out as two launches of TWO cascades each on two streams -- the first halves of both sides on `s`, the second halves on `side` -- each a
+// chain of its own (a half's pass 2 needs nothing but that half's pass 1 of the launch before): one chain's drain runs under the other's body.
+// Same kernel, same items, same bits.  1024^2 x 4: 52.1 -> 48.0 us per tick on one box (scripts/two_ctx.py; everything else that was tried -- halves of
+// other sizes, four chains, 2048^2 -- loses: a half must still fill the chip, and the two chains together must fit the Infinity Cache).
+// tick_pair_splits: would launch_tick_group split this launch when given a side stream?  The caller orders the side stream (fork / join) around it.
+bool tick_pair_splits(int n, const TickGroupArgs &g);
 
 }  // namespace ow

@@ -53,6 +53,13 @@ struct ow_context {
     int last_family = 0;  // kernel family of the most recent batch
     hipStream_t stream = nullptr;
     bool own_stream = false, own_disp = false, own_norm = false;
+    // TWO CHAINS (ow_kernels.h): tick-pair launches of four 1024^2 cascades a side go out as two launches of two cascades, the second halves on side_stream.
+    // side_active: work of the second chain is in flight that `stream` has not been made to wait for -- since the fork NOTHING but first-chain launches has
+    // been enqueued on `stream` (everything else goes through main_stream(), which joins first).
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork_ev = nullptr, side_join_ev = nullptr;
+    bool side_active = false;
+    uint64_t split_launches = 0;  // launches that went out as two chains (ow_chain_stats)
     ow::DeviceBuffers buf{};
     ow::cplx *tw_dev = nullptr, *tw_split_dev = nullptr, *tw_half_dev = nullptr;
     // generator state per invocation of update() (wave_generator.gd:13-15).  The reference keeps a reference to the caller's
@@ -153,6 +160,36 @@ struct ow_context {
     ow::SurfaceSample *query_out = nullptr;
     int query_capacity = 0;
 };
+
+// The stream everything but a first-chain launch is enqueued on or synchronised through: joins the second chain first (a no-op when none is in flight).
+// A failing event call leaves side_active set and hands back the stream all the same: the enqueue that follows reports the device's state itself.
+static hipStream_t main_stream(ow_context *c) {
+    if (c->side_active && hipEventRecord(c->side_join_ev, c->side_stream) == hipSuccess && hipStreamWaitEvent(c->stream, c->side_join_ev, 0) == hipSuccess)
+        c->side_active = false;
+    return c->stream;
+}
+// before a launch that is split: the second chain starts behind everything enqueued on `stream` so far (its cascades' previous work included)
+static bool side_fork(ow_context *c) {
+    if (c->side_active) return true;
+    if (hipEventRecord(c->side_fork_ev, c->stream) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->side_fork_ev, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    c->side_active = true;
+    return true;
+}
+// every launch of the merged shapes (tick groups, tick pairs): split over the two chains where that pays and the context may
+static hipError_t launch_group(ow_context *c, const ow::FrameArgs &args, const ow::TickGroupArgs &ga, const ow::LaunchTiming &lt = ow::LaunchTiming{}) {
+    if (c->side_stream && !lt.start && ow::tick_pair_splits(c->n, ga) && side_fork(c)) {
+        ++c->split_launches;
+        return ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, lt, c->side_stream);
+    }
+    return ow::launch_tick_group(c->n, args, ga, c->buf, main_stream(c), lt);
+}
+// a caller that brought its own stream orders its own work behind ours by that stream alone: nothing of the second chain may outlive a call
+static void join_for_caller(ow_context *c) {
+    if (!c->own_stream) (void)main_stream(c);
+}
 
 namespace {
 
@@ -272,7 +309,7 @@ ow_status ensure_scratch(ow_context *c, int slots) {
         return fail(OW_ERR_NOMEM, "hipMalloc failed for %d launch slots of scratch intermediate (%zu bytes)", slots, (size_t)slots * pl * ow::kLayers * sizeof(ow::cplx));
     }
     // the old scratch may still be in use by launches already enqueued (it is dead once they have finished: scratch of one batch)
-    if (c->buf.T && hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (c->buf.T && hipStreamSynchronize(main_stream(c)) != hipSuccess) {
         (void)hipFree(T);
         (void)hipFree(pcol);
         (void)hipFree(rrow);
@@ -366,7 +403,7 @@ ow_status refuse_faulted(const ow_context *c, uint32_t layer_mask) {
 // hipStreamSynchronize + the device status word.  layer_mask: the array layers whose bytes the caller is about to hand to ITS caller (0 for a
 // bare ow_sync), refused while they are those of a faulted batch.
 ow_status sync_stream(ow_context *c, uint32_t layer_mask) {
-    OW_HIP(hipStreamSynchronize(c->stream));
+    OW_HIP(hipStreamSynchronize(main_stream(c)));
     if (ow_status st = consume_status(c); st != OW_OK) return st;
     c->enqueued_since_sync = 0;  // everything enqueued so far has finished cleanly
     return refuse_faulted(c, layer_mask);
@@ -518,7 +555,7 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
                 ++c->spectra_skipped;  // the same thirteen words: the resident spectrum IS what the dispatch would write (spectrum_is_resident)
             } else {
                 c->spectrum_resident[idx[i]] = false;
-                OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, c->stream));
+                OW_HIP(ow::launch_spectrum(c->n, idx[i], pc, c->buf, main_stream(c)));
                 std::memcpy(c->pc_words[idx[i]].spectrum, w, sizeof(w));  // wave_generator.gd:71, in the reference's order
                 c->spectrum_resident[idx[i]] = true;
                 ++c->spectra_generated;
@@ -549,8 +586,8 @@ ow_status enqueue(ow_context *c, ow_cascade_params *params, const int *idx, int 
             if (st != OW_OK) return st;
         }
         const ow::LaunchTiming t1{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}, t2{ev ? ev[2] : nullptr, ev ? ev[3] : nullptr};
-        OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t1));  // modulate + rows + transpose (:73-80)
-        OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, c->stream, t2));  // rows + unpack (:82-85)
+        OW_HIP(ow::launch_pass1(c->n, nb, c->kernel_mode, part, c->buf, main_stream(c), t1));  // modulate + rows + transpose (:73-80)
+        OW_HIP(ow::launch_pass2(c->n, nb, c->kernel_mode, part, c->buf, main_stream(c), t2));  // rows + unpack (:82-85)
     }
     return OW_OK;
 }
@@ -674,7 +711,7 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
     };
     int cur = 0;  // scratch group of this launch's own intermediate
     if (!hit) {   // it has to be computed now: the ordinary launch, scratch slots 0 .. = group 0
-        if (!launched(ow::launch_pass1(c->n, count, c->kernel_mode, args, c->buf, c->stream))) return true;
+        if (!launched(ow::launch_pass1(c->n, count, c->kernel_mode, args, c->buf, main_stream(c)))) return true;
     } else {
         ++la.hits;
         cur = la.group[la.head];
@@ -718,7 +755,7 @@ bool lookahead_launch(ow_context *c, const LookaheadPlan &pl, ow_status *out) {
         // 512^2 x 2 13.7 | 12.7, 512^2 x 4 23.9 | 19.7, 1024^2 x 1 23.0 | 19.7; profiles/r04_lookahead_depth.txt)
         ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)count * depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
     }
-    if (!launched(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream))) return true;
+    if (!launched(launch_group(c, args, ga))) return true;
     la.armed = la.queued > 0;
     la.count = count;
     la.mode = mode;
@@ -878,7 +915,7 @@ int prearm_launch(ow_context *c, const ow_cascade_params *records, int count, co
     ga.step1 = 1;
     ga.slots = 1;
     ga.p1_compact = c->group_p1_form >= 0 ? c->group_p1_form : ((size_t)depth * c->n * c->n >= ((size_t)2 << 20) ? 1 : 0);
-    if (ow::launch_tick_group(c->n, args, ga, c->buf, c->stream) != hipSuccess) {
+    if (ow::launch_tick_group(c->n, args, ga, c->buf, main_stream(c)) != hipSuccess) {
         (void)hipGetLastError();
         la.armed = false;
         la.queued = 0;
@@ -931,7 +968,7 @@ bool flush_from_queue(ow_context *c, int left, ow_status *out) {
     b.T += (size_t)g0 * pl * ow::kLayers;
     b.pcol += (size_t)g0 * c->n;
     b.rrow += (size_t)g0 * c->n * 4;
-    const hipError_t e = ow::launch_pass2(c->n, left, c->kernel_mode, args, b, c->stream);
+    const hipError_t e = ow::launch_pass2(c->n, left, c->kernel_mode, args, b, main_stream(c));
     if (e != hipSuccess) {
         la.armed = false;
         la.queued = 0;
@@ -1035,6 +1072,12 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
             return bail(fail(OW_ERR_HIP, "hipStreamCreate failed"));
         c->own_stream = true;
     }
+    // the second chain's stream (ow_kernels.h "TWO CHAINS"): only where a launch can be split at all -- 1024^2, at least four cascades
+    if (!(cfg->flags & OW_FLAG_SINGLE_STREAM) && c->n == 1024 && c->cascades >= 4) {
+        if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side_fork_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->side_join_ev, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(OW_ERR_HIP, "second stream / events: creation failed"));
+    }
     const size_t pl = plane(c), L = (size_t)c->layers;
 #define OW_ALLOC(ptr, bytes)                                                                              \
     if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess)                                                \
@@ -1082,18 +1125,18 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
     c->buf.tw = c->tw_dev;
     c->buf.tw_split = c->tw_split_dev;
     c->buf.tw_half = c->tw_half_dev;
-    if (c->tw_half_dev && hipMemcpyAsync(c->tw_half_dev, tw_half.data(), tw_half.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    if (c->tw_half_dev && hipMemcpyAsync(c->tw_half_dev, tw_half.data(), tw_half.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, main_stream(c)) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "twiddle upload failed"));
-    if (c->tw_split_dev && hipMemcpyAsync(c->tw_split_dev, tw_split.data(), tw_split.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    if (c->tw_split_dev && hipMemcpyAsync(c->tw_split_dev, tw_split.data(), tw_split.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, main_stream(c)) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "twiddle upload failed"));
     // Vulkan images start undefined; foam must start from a defined state: zero
-    if (hipMemcpyAsync(c->tw_dev, tw.data(), tw.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.norm, 0, L * pl * sizeof(ow::u16x4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.foam, 0, L * pl * sizeof(uint16_t), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::cplx), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+    if (hipMemcpyAsync(c->tw_dev, tw.data(), tw.size() * sizeof(ow::cplx), hipMemcpyHostToDevice, main_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->buf.disp, 0, L * pl * sizeof(ow::u16x4), main_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->buf.norm, 0, L * pl * sizeof(ow::u16x4), main_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->buf.foam, 0, L * pl * sizeof(uint16_t), main_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->buf.h0, 0, L * pl * sizeof(ow::cplx), main_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->buf.omega, 0, L * pl * sizeof(float), main_stream(c)) != hipSuccess ||
+        hipStreamSynchronize(main_stream(c)) != hipSuccess)
         return bail(fail(OW_ERR_HIP, "initial upload failed: %s", hipGetErrorString(hipGetLastError())));
     for (int &sl : c->slot_of) sl = -1;
     *out = c;
@@ -1105,6 +1148,7 @@ void ow_destroy(ow_context *c) {
     int caller_dev = -1;
     (void)hipGetDevice(&caller_dev);
     (void)hipSetDevice(c->device);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->buf.h0);
     (void)hipFree(c->buf.omega);
@@ -1131,6 +1175,9 @@ void ow_destroy(ow_context *c) {
     (void)hipFree(c->query_out);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->side_fork_ev) (void)hipEventDestroy(c->side_fork_ev);
+    if (c->side_join_ev) (void)hipEventDestroy(c->side_join_ev);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
@@ -1254,6 +1301,13 @@ ow_status ow_update_all(ow_context *c, double delta, ow_cascade_params *params, 
     if (!lookahead_tick(c, delta, count, &st)) st = enqueue(c, c->pass_parameters, idx, count);
     if (st != OW_OK) return st;
     c->pass_num_cascades_remaining = 0;
+    if (!c->inside_run) join_for_caller(c);
+    return OW_OK;
+}
+
+ow_status ow_chain_stats(const ow_context *c, uint64_t *split_launches) {
+    if (!c) return fail(OW_ERR_INVALID, "null context");
+    if (split_launches) *split_launches = c->split_launches;
     return OW_OK;
 }
 
@@ -1335,7 +1389,7 @@ ow_status launch_merged(ow_context *c, const ow::FrameArgs &args, const ow::Tick
         ow_status st = next_events(c, &ev, true);
         if (st != OW_OK) return st;
     }
-    OW_HIP(ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, ow::LaunchTiming{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}));
+    OW_HIP(launch_group(c, args, ga, ow::LaunchTiming{ev ? ev[0] : nullptr, ev ? ev[1] : nullptr}));
     return OW_OK;
 }
 void finish_merged_run(ow_context *c, ow::FrameArgs &args, const ow_cascade_params *params, int count, int last_batch, int family, int depth) {
@@ -1697,6 +1751,7 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     ra.last_count = count;
     ra.last_delta = delta;
     if (st != OW_OK) ra.armed = false;
+    join_for_caller(c);
     return st;
 }
 
@@ -1838,8 +1893,8 @@ ow_status ow_get_maps(ow_context *c, int32_t cascade, void *disp, void *norm) {
     if (st != OW_OK) return st;
     OW_HIP(hipSetDevice(c->device));
     const size_t bytes = plane(c) * sizeof(ow::u16x4);
-    if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
-    if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, c->stream));
+    if (disp) OW_HIP(hipMemcpyAsync(disp, c->buf.disp + cascade * plane(c), bytes, hipMemcpyDeviceToHost, main_stream(c)));
+    if (norm) OW_HIP(hipMemcpyAsync(norm, c->buf.norm + cascade * plane(c), bytes, hipMemcpyDeviceToHost, main_stream(c)));
     return sync_stream(c, 1u << cascade);
 }
 
@@ -1881,11 +1936,11 @@ ow_status ow_readback_begin(ow_context *c, uint32_t mask) {
         ow::u16x4 *sd = c->snap_dev + (size_t)i * pl, *sn = c->snap_dev + (L + i) * pl;
         ow::u16x4 *hd = c->snap_host + (size_t)i * pl, *hn = c->snap_host + (L + i) * pl;
         // the snapshot slot may still be feeding an earlier PCIe copy
-        if (c->copy_pending[i]) OW_HIP(hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
+        if (c->copy_pending[i]) OW_HIP(hipStreamWaitEvent(main_stream(c), c->copy_done[i], 0));
         c->readback_faulted &= ~(1u << i);  // a new snapshot of this layer
-        OW_HIP(hipMemcpyAsync(sd, c->buf.disp + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
-        OW_HIP(hipMemcpyAsync(sn, c->buf.norm + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, c->stream));
-        OW_HIP(hipEventRecord(c->snap_ready[i], c->stream));
+        OW_HIP(hipMemcpyAsync(sd, c->buf.disp + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, main_stream(c)));
+        OW_HIP(hipMemcpyAsync(sn, c->buf.norm + (size_t)i * pl, bytes, hipMemcpyDeviceToDevice, main_stream(c)));
+        OW_HIP(hipEventRecord(c->snap_ready[i], main_stream(c)));
         OW_HIP(hipStreamWaitEvent(c->copy_stream, c->snap_ready[i], 0));
         OW_HIP(hipMemcpyAsync(hd, sd, bytes, hipMemcpyDeviceToHost, c->copy_stream));
         OW_HIP(hipMemcpyAsync(hn, sn, bytes, hipMemcpyDeviceToHost, c->copy_stream));
@@ -1940,9 +1995,9 @@ ow_status ow_sample_surface(ow_context *c, const float *xz, int32_t count, const
     ow::SurfaceScales sc;
     std::memset(&sc, 0, sizeof(sc));
     std::memcpy(sc.s, map_scales, (size_t)num_cascades * 4 * sizeof(float));
-    OW_HIP(hipMemcpyAsync(c->query_xz, xz, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    OW_HIP(ow::launch_sample_surface(c->n, num_cascades, c->buf, c->query_xz, count, sc, c->query_out, c->stream));
-    OW_HIP(hipMemcpyAsync(out, c->query_out, (size_t)count * sizeof(ow::SurfaceSample), hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipMemcpyAsync(c->query_xz, xz, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, main_stream(c)));
+    OW_HIP(ow::launch_sample_surface(c->n, num_cascades, c->buf, c->query_xz, count, sc, c->query_out, main_stream(c)));
+    OW_HIP(hipMemcpyAsync(out, c->query_out, (size_t)count * sizeof(ow::SurfaceSample), hipMemcpyDeviceToHost, main_stream(c)));
     return sync_stream(c, (1u << num_cascades) - 1u);
 }
 
@@ -1958,9 +2013,9 @@ ow_status ow_set_normal_map(ow_context *c, int32_t cascade, const void *norm) {
     const uint16_t *src = static_cast<const uint16_t *>(norm);
     for (size_t xp = 0; xp < n; ++xp)
         for (size_t yp = 0; yp < n; ++yp) foam[xp * n + (yp % tl) * 16 + yp / tl] = src[(xp * n + yp) * 4 + 3];
-    OW_HIP(hipMemcpyAsync(c->buf.norm + cascade * plane(c), norm, plane(c) * sizeof(ow::u16x4), hipMemcpyHostToDevice, c->stream));
-    OW_HIP(hipMemcpyAsync(c->buf.foam + cascade * plane(c), foam.data(), plane(c) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
+    OW_HIP(hipMemcpyAsync(c->buf.norm + cascade * plane(c), norm, plane(c) * sizeof(ow::u16x4), hipMemcpyHostToDevice, main_stream(c)));
+    OW_HIP(hipMemcpyAsync(c->buf.foam + cascade * plane(c), foam.data(), plane(c) * sizeof(uint16_t), hipMemcpyHostToDevice, main_stream(c)));
+    OW_HIP(hipStreamSynchronize(main_stream(c)));
     return OW_OK;
 }
 
@@ -1970,7 +2025,7 @@ ow_status ow_get_maps_f32(ow_context *c, int32_t cascade, float *out) {
     if (!c->buf.f32) return fail(OW_ERR_STATE, "context was created without OW_FLAG_DEBUG_F32");
     if (!out) return fail(OW_ERR_INVALID, "null output");
     OW_HIP(hipSetDevice(c->device));
-    OW_HIP(hipMemcpyAsync(out, c->buf.f32 + cascade * plane(c) * 8, plane(c) * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OW_HIP(hipMemcpyAsync(out, c->buf.f32 + cascade * plane(c) * 8, plane(c) * 8 * sizeof(float), hipMemcpyDeviceToHost, main_stream(c)));
     return sync_stream(c, 1u << cascade);
 }
 
@@ -1981,10 +2036,10 @@ ow_status ow_get_spectrum(ow_context *c, int32_t cascade, float *h0, float *omeg
     std::vector<ow::cplx> a;
     if (h0) {
         a.resize(plane(c));
-        OW_HIP(hipMemcpyAsync(a.data(), c->buf.h0 + cascade * plane(c), plane(c) * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
+        OW_HIP(hipMemcpyAsync(a.data(), c->buf.h0 + cascade * plane(c), plane(c) * sizeof(ow::cplx), hipMemcpyDeviceToHost, main_stream(c)));
     }
-    if (omega) OW_HIP(hipMemcpyAsync(omega, c->buf.omega + cascade * plane(c), plane(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
+    if (omega) OW_HIP(hipMemcpyAsync(omega, c->buf.omega + cascade * plane(c), plane(c) * sizeof(float), hipMemcpyDeviceToHost, main_stream(c)));
+    OW_HIP(hipStreamSynchronize(main_stream(c)));
     if (h0) {  // rebuild the reference's texel (h0(k), conj(h0(-k))) from the stored half (spectrum_compute.glsl:121-124)
         const size_t n = (size_t)c->n;
         for (size_t y = 0; y < n; ++y)
@@ -2021,8 +2076,8 @@ ow_status ow_get_intermediate(ow_context *c, int32_t cascade, float *out) {
     if (c->last_family >= 3)
         return fail(OW_ERR_STATE, "the most recent batch used the compact (three-layer) intermediate, which has no counterpart in the "
                                   "reference's fft_buffer: create the context with OW_FLAG_KERNELS_STANDARD to inspect it");
-    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + (size_t)c->slot_of[cascade] * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, c->stream));
-    OW_HIP(hipStreamSynchronize(c->stream));
+    OW_HIP(hipMemcpyAsync(t.data(), c->buf.T + (size_t)c->slot_of[cascade] * pl * ow::kLayers, t.size() * sizeof(ow::cplx), hipMemcpyDeviceToHost, main_stream(c)));
+    OW_HIP(hipStreamSynchronize(main_stream(c)));
     // device layout T[layer][y/16][x'][y%16]  ->  reference half-0-after-transpose layout [layer][row = x'][col = y].
     // The device rows carry the x' half of the ifftshift sign, (-1)^x' (see Pass1::rot): taken out again here.
     for (int layer = 0; layer < ow::kLayers; ++layer)
@@ -2048,11 +2103,11 @@ ow_status ow_probe_kernel_times(ow_context *c, int32_t reps, float *p1_ms, float
     float a = 0, b = 0;
     auto run = [&]() -> ow_status {
         for (auto &x : e) OW_HIP(hipEventCreate(&x));
-        OW_HIP(hipEventRecord(e[0], c->stream));
-        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
-        OW_HIP(hipEventRecord(e[1], c->stream));
-        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, c->stream));
-        OW_HIP(hipEventRecord(e[2], c->stream));
+        OW_HIP(hipEventRecord(e[0], main_stream(c)));
+        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass1(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, main_stream(c)));
+        OW_HIP(hipEventRecord(e[1], main_stream(c)));
+        for (int i = 0; i < reps; ++i) OW_HIP(ow::launch_pass2(c->n, c->last_count, c->kernel_mode, c->last_args, c->buf, main_stream(c)));
+        OW_HIP(hipEventRecord(e[2], main_stream(c)));
         OW_HIP(hipEventSynchronize(e[2]));
         OW_HIP(hipEventElapsedTime(&a, e[0], e[1]));
         OW_HIP(hipEventElapsedTime(&b, e[1], e[2]));

@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (OW_FLAG_ALWAYS_REGENERATE_SPECTRUM, OW_FLAG_LAZY_SCRATCH, OW_FLAG_DEBUG_F32, OW_FLAG_GROUP_P1_COMPACT, OW_FLAG_GROUP_P1_LP, OW_FLAG_GROUP_P2_PIPE, OW_FLAG_GROUP_P2_PLAIN, OW_FLAG_KERNELS_COMPACT,
+from ._lib import (OW_FLAG_ALWAYS_REGENERATE_SPECTRUM, OW_FLAG_LAZY_SCRATCH, OW_FLAG_SINGLE_STREAM, OW_FLAG_DEBUG_F32, OW_FLAG_GROUP_P1_COMPACT, OW_FLAG_GROUP_P1_LP, OW_FLAG_GROUP_P2_PIPE, OW_FLAG_GROUP_P2_PLAIN, OW_FLAG_KERNELS_COMPACT,
                    OW_FLAG_KERNELS_LAYER_PARALLEL, OW_FLAG_KERNELS_STANDARD, OW_FLAG_NO_TICK_GROUPS, OW_FLAG_RUN_AS_CALLS, OW_FLAG_RUN_AS_REFERENCE_SCHEDULE,
                    ow_cascade_params, ow_config)
 
@@ -107,6 +107,7 @@ class WaveGenerator:
         self.run_as_reference = False  # True: run() issues update() + one _process() per cascade, tick by tick (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE)
         self.always_regenerate_spectrum = False  # True: every dirty flag launches the spectrum kernel, as the reference does (OW_FLAG_ALWAYS_REGENERATE_SPECTRUM)
         self.lazy_scratch = False      # True: ow_create allocates one batch of scratch, the look-ahead's share on first use (OW_FLAG_LAZY_SCRATCH)
+        self.single_stream = False     # True: tick-pair launches of four 1024^2 cascades stay whole, on the one stream (OW_FLAG_SINGLE_STREAM; default: two chains on two streams)
         self.group_forms = (None, None)  # tests: pin the tick groups' work-item forms -- ("lp" | "compact", "plain" | "pipe"); None = the runtime's choice
         self.device_id = -1
         self.stream = None
@@ -126,7 +127,7 @@ class WaveGenerator:
                         depth=float(self.depth), stream=self.stream, displacement_map=self.external_maps[0],
                         normal_map=self.external_maps[1], flags=(OW_FLAG_DEBUG_F32 if self.debug_f32 else 0) | {None: 0, "lp": OW_FLAG_GROUP_P1_LP, "compact": OW_FLAG_GROUP_P1_COMPACT}[self.group_forms[0]] |
                         {None: 0, "plain": OW_FLAG_GROUP_P2_PLAIN, "pipe": OW_FLAG_GROUP_P2_PIPE}[self.group_forms[1]] | (0 if self.tick_groups else OW_FLAG_NO_TICK_GROUPS) | (OW_FLAG_RUN_AS_CALLS if self.run_as_calls else 0) | (OW_FLAG_RUN_AS_REFERENCE_SCHEDULE if self.run_as_reference else 0) |
-                        (OW_FLAG_ALWAYS_REGENERATE_SPECTRUM if self.always_regenerate_spectrum else 0) | (OW_FLAG_LAZY_SCRATCH if self.lazy_scratch else 0) |
+                        (OW_FLAG_ALWAYS_REGENERATE_SPECTRUM if self.always_regenerate_spectrum else 0) | (OW_FLAG_LAZY_SCRATCH if self.lazy_scratch else 0) | (OW_FLAG_SINGLE_STREAM if self.single_stream else 0) |
                         {None: 0, "standard": OW_FLAG_KERNELS_STANDARD, "layer_parallel": OW_FLAG_KERNELS_LAYER_PARALLEL,
                                "compact": OW_FLAG_KERNELS_COMPACT,
                                "layer_parallel_compact": OW_FLAG_KERNELS_LAYER_PARALLEL | OW_FLAG_KERNELS_COMPACT}[self.kernels])
@@ -305,6 +306,12 @@ class WaveGenerator:
         h, sp = C.c_uint64(), C.c_uint64()
         _lib.check(self._lib.ow_lookahead_stats(self.context, C.byref(h), C.byref(sp)))
         return h.value, sp.value
+
+    def chain_stats(self):
+        """launches that went out as two chains on two streams (1024^2, four cascades a side; OW_FLAG_SINGLE_STREAM keeps them whole)"""
+        n = C.c_uint64()
+        _lib.check(self._lib.ow_chain_stats(self.context, C.byref(n)))
+        return n.value
 
     def spectrum_stats(self):
         """(generated, skipped): spectrum kernels launched, and dirty flags consumed because the resident spectrum had been generated from the

@@ -132,6 +132,15 @@ typedef struct ow_config {
  * that speculates (one hipMalloc + stream synchronisation inside that call, none afterwards).  For contexts that are only driven through ow_run's
  * tick groups, or many shards on one device; the default keeps every per-frame call free of allocations. */
 #define OW_FLAG_LAZY_SCRATCH 0x2000u
+/* TWO CHAINS (round 6; 1024^2 with four or more cascades).  A tick-pair launch of four 1024^2 cascades on either side is two generations of blocks, and the
+ * kernel boundary between two such launches costs a tenth of them (the chip drains and fills again).  Cascades are independent: ow_run and ow_update_all
+ * issue such a launch as TWO launches of two cascades each, the second on a stream of the context's own, each half a chain by itself -- one chain's drain
+ * runs under the other's body (1024^2 x 4: 52.1 -> 48.0 us per tick on one box; bit-identical maps: the same kernel on the same items).  Everything else
+ * the context enqueues or waits for is ordered behind BOTH chains (ow_sync, the readbacks, ow_get_maps, ow_process, ... join first); where the context runs
+ * on a stream of the CALLER's (ow_config.stream), the second chain is joined before ow_run / ow_update_all return, so that work the caller enqueues on that
+ * stream afterwards finds every map complete, as before.  This flag keeps every launch whole, on the one stream (tests, A/B).  ow_chain_stats: launches
+ * that went out as two chains. */
+#define OW_FLAG_SINGLE_STREAM 0x4000u
 
 typedef struct ow_context ow_context;
 
@@ -212,6 +221,7 @@ ow_status ow_lookahead_stats(const ow_context *ctx, uint64_t *hits, uint64_t *sp
  * slider dragged at 50 updates per second no longer costs a spectrum per cascade per update.  ow_get_cascade_params then shows the flag
  * already cleared.  ow_spectrum_stats: spectrum kernels launched by this context, and dirty flags consumed without one. */
 ow_status ow_spectrum_stats(const ow_context *ctx, uint64_t *generated, uint64_t *skipped);
+ow_status ow_chain_stats(const ow_context *ctx, uint64_t *split_launches);   /* OW_FLAG_SINGLE_STREAM */
 
 /* `frames` consecutive ow_update_all() ticks with the same delta, enqueued back to back (the reference's
  * "1000-frame loop" without a host round trip per tick).  Equivalent to calling ow_update_all `frames` times: only the state a run leaves

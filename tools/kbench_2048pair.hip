@@ -167,28 +167,6 @@ int main(int argc, char **argv) {
     printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
     printf("  one launch per pass (again)  : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
     printf("  k_tick_pair_c_split (again)  : %8.2f\n", time_it(pair, iters * C, s));
-    auto pair2 = [&](int i) { hipLaunchKernelGGL((k_tick_pair2_c_split<N, false>), dim3((g.n2 + g.n1) / 2), dim3(PT), 0, s, buf, pair_args(i), (Stamp *)nullptr); };
-    auto pair21 = [&](int i) { hipLaunchKernelGGL((k_tick_pair2_c_split<N, false, false, 1>), dim3(g.n2 + g.n1), dim3(PT), 0, s, buf, pair_args(i), (Stamp *)nullptr); };
-    for (int r = 0; r < 3; ++r) {
-        printf("  k_tick_pair2_c_split<1 item> : %8.2f   (the two-item kernel's code, one item per block)\n", time_it(pair21, iters * C, s));
-        printf("  k_tick_pair2_c_split stream  : %8.2f   (two items per block)\n", time_it(pair2, iters * C, s));
-        printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
-    }
-    {   // same bits?  seven launches of either kernel from the same state
-        auto snapshot = [&](auto launch) {
-            CK(hipMemset(buf.foam, 0, L * pl * 2)); CK(hipMemset(buf.norm, 0, L * pl * 8)); CK(hipMemset(buf.disp, 0, L * pl * 8)); CK(hipMemset(buf.T, 0, 2 * pl * 32));
-            CK(hipMemset(buf.pcol, 0, 2 * (size_t)N * 8)); CK(hipMemset(buf.rrow, 0, 2 * (size_t)N * 32));
-            for (int i = 0; i < 7; ++i) launch(i);
-            CK(hipStreamSynchronize(s));
-            std::vector<unsigned char> v(L * pl * 18 + 2 * pl * 32);
-            CK(hipMemcpy(v.data(), buf.disp, L * pl * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data() + L * pl * 8, buf.norm, L * pl * 8, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(v.data() + L * pl * 16, buf.foam, L * pl * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data() + L * pl * 18, buf.T, 2 * pl * 32, hipMemcpyDeviceToHost));
-            return v;
-        };
-        const auto va = snapshot(pair), vb = snapshot(pair2);
-        size_t diff = 0, nz = 0; for (size_t i = 0; i < va.size(); ++i) { diff += va[i] != vb[i]; nz += va[i] != 0; }
-        printf("  two items per block against one: %zu of %zu bytes differ (%zu non-zero)\n", diff, va.size(), nz);
-    }
     uint32_t status = 0; CK(hipMemcpy(&status, buf.status, 4, hipMemcpyDeviceToHost));
     printf("  status word 0x%x\n", status);
 
@@ -235,34 +213,6 @@ int main(int argc, char **argv) {
         for (auto &x : h) if (x.t[15] >= 1000ull && x.t[15] < 1000ull + N) { s1 += (double)(x.t[0] - t0); ++c1; }
         if (c1) printf("  pass-1 waves (%d): average start %.0f clocks into the launch\n", c1, s1 / c1);
         timeline(h, W2);
-    }
-    {
-        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL((k_tick_pair2_c_split<N, false, true>), dim3((g.n2 + g.n1) / 2), dim3(PT), 0, s, buf, pair_args(i), st);
-        CK(hipStreamSynchronize(s));
-        std::vector<Stamp> h((size_t)(g.n2 + g.n1) / 2 * W2); CK(hipMemcpy(h.data(), st, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
-        unsigned long long r0 = ~0ull; for (auto &x : h) if (x.rt0) r0 = std::min(r0, x.rt0);
-        std::vector<double> e2, e1, m2; for (size_t i = 0; i < h.size(); i += W2) { (h[i].t[15] == 100000ull ? e2 : e1).push_back((double)(h[i].rt1 - r0) * 0.01); }
-        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (v.size() - 1))]; };
-        {
-            std::vector<double> l1, l2, st2;
-            for (size_t i = 0; i < h.size(); i += W2) {
-                const Stamp &x = h[i];
-                if (x.t[15] != 100000ull || x.t[14] == x.t[0]) continue;
-                const double us_per_clk = (double)(x.rt1 - x.rt0) * 0.01 / (double)(x.t[14] - x.t[0]);
-                l1.push_back((double)(x.t[1] - x.t[0]) * us_per_clk); l2.push_back((double)(x.t[14] - x.t[1]) * us_per_clk);
-            }
-            printf("  pass-2 blocks: first item p10/p50/p90 %6.2f %6.2f %6.2f us, second item %6.2f %6.2f %6.2f us\n", pct(l1, .1), pct(l1, .5), pct(l1, .9), pct(l2, .1), pct(l2, .5), pct(l2, .9));
-            std::vector<double> a1, a2;
-            for (size_t i = 0; i < h.size(); i += W2) {
-                const Stamp &x = h[i];
-                if (x.t[15] == 100000ull || x.t[14] == x.t[0]) continue;
-                const double us_per_clk = (double)(x.rt1 - x.rt0) * 0.01 / (double)(x.t[14] - x.t[0]);
-                a1.push_back((double)(x.t[1] - x.t[0]) * us_per_clk); a2.push_back((double)(x.t[14] - x.t[1]) * us_per_clk);
-            }
-            printf("  pass-1 blocks: until the second item's loads are out p10/p50/p90 %6.2f %6.2f %6.2f us, from there to the end %6.2f %6.2f %6.2f us\n", pct(a1, .1), pct(a1, .5), pct(a1, .9), pct(a2, .1), pct(a2, .5), pct(a2, .9));
-        }
-        printf("k_tick_pair2_c_split (two items per block): blocks end (us since the first wave) pass 2 p10/p50/p90/max %6.2f %6.2f %6.2f %6.2f   pass 1 %6.2f %6.2f %6.2f %6.2f\n",
-               pct(e2, .1), pct(e2, .5), pct(e2, .9), pct(e2, 1.0), pct(e1, .1), pct(e1, .5), pct(e1, .9), pct(e1, 1.0));
     }
     return 0;
 }
