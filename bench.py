@@ -728,6 +728,9 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
     #      the quantity a rocprofv3 kernel trace reports ----
     probe = 400  # (independent of --steps: a 50-tick probe right after an idle moment measured the clock ramp, 33 us where 400 ticks give 27.7)
     merged = launch_mode in MERGED_KERNEL
+    # two chains (round 6): did the timed regions' tick-pair launches go out as two launches of half the cascades on two streams?  (asked BEFORE the
+    # probes below: a launch that carries timing events stays whole)
+    chains = 2 if (merged and gen.chain_stats() > 0) else 1
     gl_ms = gl_n = 0
     if merged:  # ow_run's merged launches (tick groups / tick pairs), each timed on its own
         gen.timing(2)
@@ -819,8 +822,13 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
         per_launch = C // batches if C % batches == 0 else round(C / batches, 3)
         dom_bpt, dom_contract, texels = (k1 + k2) * GROUP - 4 * (GROUP - 1), sum(CONTRACT_BYTES) * GROUP, n * n * C / batches
         dom_ms = elapsed / ticks * 1e3 * GROUP / batches          # time per tick x ticks per launch
-        achieved = gbps(dom_bpt * texels, dom_ms)
-        contract = gbps(dom_contract * texels, dom_ms)
+        if chains == 2:
+            # each launch of the timed regions went out as TWO launches of half its cascades on two streams, each stream a chain of back-to-back launches
+            # of its own: a launch still lasts one tick (x ticks per launch / batches), two of them run at any time, each moves half the bytes
+            per_launch = per_launch // 2 if isinstance(per_launch, int) and per_launch % 2 == 0 else per_launch / 2
+            texels = texels / 2
+        achieved = chains * gbps(dom_bpt * texels, dom_ms)
+        contract = chains * gbps(dom_contract * texels, dom_ms)
         events_achieved = gbps(((k1 + k2) * T - 4 * (T - groups)) * n * n * C, gl_ms * gl_n)
     else:
         achieved = gbps(dom_bpt * texels, dom_ms)
@@ -877,7 +885,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
                    "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
                    "launches": (f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp)"
                                 if launch_mode == "tick_groups_compact" else
-                                "tick pairs: pass 2 of one batch and pass 1 of the next in one launch (k_tick_pair_c)") if grouped
+                                "tick pairs: pass 2 of one batch and pass 1 of the next in one launch (k_tick_pair_c)" +
+                                (", as two chains: two launches of two cascades each on two streams" if chains > 1 else "")) if grouped
                                else "one pair of launches per batch and tick",
                    "gather": (f"{args.gather}, every {gather_every} ticks (timed), " + ("serialised" if args.no_overlap else "snapshot + side stream"))
                              if (world > 1 and gather_every) else (f"{args.gather}, final, untimed" if world > 1 else "none"),
@@ -915,7 +924,9 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
                                         if "seconds" in refsched else refsched)} if refsched else {}),
             "bytes_per_texel": dom_bpt, "bytes_per_launch": int(dom_bpt * texels),
             "bytes_basis": "design bytes of the launched kernel family (DESIGN.md section 3)" +
-                           (f"; one launch = both passes of {max(1, group_depth)} tick(s) of {per_launch} cascade(s), duration = timed region / launches" if grouped else ""),
+                           (f"; one launch = both passes of {max(1, group_depth)} tick(s) of {per_launch} cascade(s), duration = timed region / launches" if grouped else "") +
+                           (f" of ONE of the {chains} streams: {chains} such launches run at any time (two chains), achieved = {chains} x bytes_per_launch / avg_launch_ms" if chains > 1 else ""),
+            **({"concurrent_launches": chains} if chains > 1 else {}),
             "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBPS, 4), "copy_ceiling": COPY_CEILING_GBPS,
             # SURVEY 8d's contract bytes (four-layer FP32 intermediate, 104 B/texel per map) over the same duration: a
             # figure of merit against a design that moves more, NOT a bandwidth (it can exceed the copy ceiling)
@@ -923,7 +934,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of an earlier visit, NOT measured by this run" if traffic else None,
             "traffic_gbps": round(gbps(traffic, dom_ms), 1) if traffic else None,
             "avg_launch_ms": round(dom_ms, 5), "pass1_ms": round(p1_ms, 5), "pass2_ms": round(p2_ms, 5),
-            **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n} if grouped else {}),
+            **({"avg_launch_ms_events": round(gl_ms, 5), "achieved_events": round(events_achieved, 1), "launches_timed_events": gl_n,
+                **({"events_note": "a launch that carries timing events stays whole, on one stream: these are the one-stream launches of all the cascades"} if chains > 1 else {})} if grouped else {}),
             "launches_timed": launches, "launch_pairs_per_tick": round(pairs_per_tick, 3), "cascades_per_launch": per_launch,
             "residency": res,
             **({"other_configs": other_configs} if other_configs is not None else {}),
@@ -1035,14 +1047,14 @@ def main():
                 # roofline.traffic measured by THIS run (after the timed work: the profiled child process shares the GPU with nothing)
                 rf = out["roofline"]
                 try:
-                    got, detail = measure_traffic(n, C, rf["kernel"], seamless=rf["kernel"].startswith("k_tick_pair_c") and rf["cascades_per_launch"] == C)
+                    got, detail = measure_traffic(n, C, rf["kernel"], seamless=rf["kernel"].startswith("k_tick_pair_c") and rf["cascades_per_launch"] * rf.get("concurrent_launches", 1) == C)
                     rf["traffic"] = got
                     # (FETCH_SIZE[KB] * 1024 * 2 (gfx950) + WRITE_SIZE[KB] * 1024 per full launch -- every pair launch of a single-batch run carries both passes --
                     #  between the XCD L2s and the fabric, Infinity-Cache hits included: DESIGN.md section 6)
                     rf["traffic_source"] = "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, 81 ticks through ow_run), gfx950 correction applied"
                     rf["traffic_detail"] = detail
                     rf["traffic_bytes_per_texel"] = round(got / max(1, rf["bytes_per_launch"]) * rf["bytes_per_texel"], 2)
-                    rf["traffic_gbps"] = round(got / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                    rf["traffic_gbps"] = round(rf.get("concurrent_launches", 1) * got / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
                 except Exception as e:  # noqa: BLE001  (the profiling leg must not cost the line: the earlier visit's figure stays, labelled)
                     rf["traffic_measurement_failed"] = f"{type(e).__name__}: {str(e)[:200]}"
             if cpu is not None:
