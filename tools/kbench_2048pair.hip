@@ -5,6 +5,7 @@
 //   tools/kbench_2048pair [cascades = 4] [iterations = 40]
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -167,6 +168,42 @@ int main(int argc, char **argv) {
     printf("  k_tick_pair_c_split stream   : %8.2f\n", time_it(pair, iters * C, s));
     printf("  one launch per pass (again)  : %8.2f\n", time_it([&](int i) { p1(i); p2(i); }, iters * C, s));
     printf("  k_tick_pair_c_split (again)  : %8.2f\n", time_it(pair, iters * C, s));
+    if (argc > 3) {  // EXPERIMENT (round 6): pass 1 and pass 2 as SEPARATE half-filled launches of the pair kernel on two streams, each waiting for the other's
+        // previous launch by an event (pass 2 of tick i needs pass 1 of tick i = B_{i-1}; pass 1 of tick i + 1 needs the scratch pass 2 of tick i - 1 read = A_{i-1}):
+        // at any time one launch of each kind is in flight, a skewed pair, and the drain of one runs under the body of the other.  Timing only (the data are not chained).
+        hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        constexpr int R = 8;
+        hipEvent_t ea[R], eb[R];
+        for (int i = 0; i < R; ++i) { CK(hipEventCreateWithFlags(&ea[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eb[i], hipEventDisableTiming)); }
+        const bool events = atoi(argv[3]) == 1;
+        auto run = [&](int n) {
+            for (int i = 0; i < n; ++i) {
+                PairArgs h1 = pair_args(i), h2 = pair_args(i);
+                h1.n2 = 0; h2.n1 = 0;
+                if (events && i > 0) CK(hipStreamWaitEvent(sb, ea[(i - 1) % R], 0));
+                hipLaunchKernelGGL((k_tick_pair_c_split<N, false>), dim3(h1.n1), dim3(PT), 0, sb, buf, h1, (Stamp *)nullptr);
+                if (events) CK(hipEventRecord(eb[i % R], sb));
+                if (events && i > 0) CK(hipStreamWaitEvent(sa, eb[(i - 1) % R], 0));
+                hipLaunchKernelGGL((k_tick_pair_c_split<N, false>), dim3(h2.n2), dim3(PT), 0, sa, buf, h2, (Stamp *)nullptr);
+                if (events) CK(hipEventRecord(ea[i % R], sa));
+            }
+            CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
+        };
+        run(20);
+        for (int rep = 0; rep < 3; ++rep) {
+            const int n = iters * C * 4;
+            const auto t0 = std::chrono::steady_clock::now();
+            run(n);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            printf("  two streams, one launch per pass each%s: %8.2f us per cascade (host clock, %d ticks)\n", events ? ", event-chained" : ", NO dependencies (upper bound)", us / n, n);
+            CK(hipStreamSynchronize(s));
+            const auto t1 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; ++i) pair(i);
+            CK(hipStreamSynchronize(s));
+            printf("  k_tick_pair_c_split stream (host clock)  : %8.2f\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / n);
+        }
+        return 0;
+    }
     uint32_t status = 0; CK(hipMemcpy(&status, buf.status, 4, hipMemcpyDeviceToHost));
     printf("  status word 0x%x\n", status);
 
