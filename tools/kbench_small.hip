@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -210,6 +211,49 @@ int main(int argc, char **argv) {
         const float tg = time_it(grp, std::max(50, iters / D), s);
         printf("tick group: D = %d, pass-1 items %s, pass 2 %s: %d pass-2 blocks + %d x %d pass-1 blocks of %d threads: %7.2f us per launch = %6.2f us per tick\n", D,
                p1c ? "compact" : "layer-parallel", pipe ? "pipelined" : "plain", ga.n2, D, ga.n1, plan_lp_threads(N), tg, tg / D);
+        if (argc > 6) {  // EXPERIMENT (round 6): the group's pass 2 (a serial chain through the ticks) and its pass 1 (independent of everything but scratch) as TWO
+            // launches on two streams -- mode 1: event-chained (pass 2 of group k waits for pass 1 of group k, pass 1 of group k + 2 for pass 2 of group k),
+            // mode 2: no dependencies at all (the bound).  Timing only.
+            const int mode = atoi(argv[6]);
+            hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+            constexpr int R = 8;
+            hipEvent_t ea[R], eb[R];
+            for (int i = 0; i < R; ++i) { CK(hipEventCreateWithFlags(&ea[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eb[i], hipEventDisableTiming)); }
+            auto go = [&](const TickGroupArgs &h, int nblocks, hipStream_t st) {
+                const dim3 gr(nblocks), bl(plan_lp_threads(N));
+                if (pipe) hipLaunchKernelGGL((k_tick_group_c_lp<N, false, false, true>), gr, bl, 0, st, gb, args, h, (Stamp *)nullptr);
+                else hipLaunchKernelGGL((k_tick_group_c_lp<N, false, false, false>), gr, bl, 0, st, gb, args, h, (Stamp *)nullptr);
+            };
+            auto run = [&](int n) {
+                for (int i = 0; i < n; ++i) {
+                    fill();
+                    TickGroupArgs h1 = ga, h2 = ga;
+                    h1.d2 = 0; h1.n2 = 0;   // pass 1 of D ticks
+                    h2.d1 = 0;              // pass 2 of D ticks
+                    if (mode == 1 && i > 1) CK(hipStreamWaitEvent(sb, ea[(i - 2) % R], 0));
+                    go(h1, D * ga.n1, sb);
+                    if (mode == 1) CK(hipEventRecord(eb[i % R], sb));
+                    if (mode == 1 && i > 0) CK(hipStreamWaitEvent(sa, eb[(i - 1) % R], 0));
+                    go(h2, ga.n2, sa);
+                    if (mode == 1) CK(hipEventRecord(ea[i % R], sa));
+                }
+                CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
+            };
+            run(20);
+            for (int rep = 0; rep < 3; ++rep) {
+                const int n = std::max(200, iters / D);
+                auto t0 = std::chrono::steady_clock::now();
+                run(n);
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                auto t1 = std::chrono::steady_clock::now();
+                for (int i = 0; i < n; ++i) grp();
+                CK(hipStreamSynchronize(s));
+                const double us1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+                printf("  two streams (pass 2 | pass 1)%s: %7.2f us per group = %6.2f per tick;   one launch per group: %7.2f = %6.2f per tick (host clock, %d groups)\n",
+                       mode == 1 ? ", event-chained" : ", NO dependencies (bound)", us / n, us / n / D, us1 / n, us1 / n / D, n);
+            }
+            return 0;
+        }
         Stamp *gs;
         CK(hipMalloc(&gs, sizeof(Stamp) * (size_t)blocks * wpb));
         CK(hipMemset(gs, 0, sizeof(Stamp) * (size_t)blocks * wpb));
