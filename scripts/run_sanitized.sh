@@ -15,6 +15,7 @@ ASAN_TESTS="tests/test_lookahead.py tests/test_run_after_run.py tests/test_spect
 say "== ASan + UBSan (host side; device code unchanged): LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so ASAN_OPTIONS=$ASAN_OPTIONS"
 say "   python -m pytest $ASAN_TESTS -m gpu -q"
 LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 2400 python -m pytest $ASAN_TESTS -m gpu -q --timeout 1200 -p no:cacheprovider > $O/asan_pytest.log 2>&1
+LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 1200 python -m pytest tests/test_two_chains.py -k "not callers_stream" -m gpu -q --timeout 600 -p no:cacheprovider > $O/asan_pytest_chains.log 2>&1; say "   tests/test_two_chains.py -k 'not callers_stream' (that one imports torch): $(tail -1 $O/asan_pytest_chains.log)"
 LD_PRELOAD=$ASAN_RT OCEAN_WAVES_LIB=$V/asan.so timeout 1200 python -m pytest tests/test_group.py -k "not c4_exact_shape" -m gpu -q --timeout 600 -p no:cacheprovider > $O/asan_pytest_group.log 2>&1; say "   tests/test_group.py -k 'not c4_exact_shape' (that one spends its time in the OpenMP oracle): $(tail -1 $O/asan_pytest_group.log)"
 say "   rc=$?  $(tail -1 $O/asan_pytest.log)"
 say "   python -m pytest tests/test_runtime_contract.py tests/test_interop.py -m gpu -q      (these import torch into the sanitized process)"
