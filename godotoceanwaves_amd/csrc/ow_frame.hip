@@ -102,9 +102,12 @@ static hipError_t launch2(int slots, int mode, const FrameArgs &args, const Devi
 }
 
 // ---- tick pairs on the compact family (k_tick_pair_c): k_pass2c's blocks of one batch, k_pass1c's of the next, in one launch ----
-constexpr int kChainSlots = 4;  // a side of a tick-pair launch that two chains share: four cascades (two each)
+static int chain_slots(int n) {  // a side of a tick-pair launch that two chains share: four 1024^2 cascades (two each), eight 512^2 cascades (four each)
+    return n == 1024 ? 4 : n == 512 ? 8 : 0;
+}
 bool tick_pair_splits(int n, const TickGroupArgs &g) {
-    return n == 1024 && g.pair_compact && (g.slots2 == kChainSlots || g.slots2 == 0) && (g.slots1 == kChainSlots || g.slots1 == 0) && g.slots2 + g.slots1 > 0;
+    const int cs = chain_slots(n);
+    return cs > 0 && g.pair_compact && (g.slots2 == cs || g.slots2 == 0) && (g.slots1 == cs || g.slots1 == 0) && g.slots2 + g.slots1 > 0;
 }
 template <int N, bool F32>
 static hipError_t launch_pair_n(const FrameArgs &args, TickGroupArgs g, const DeviceBuffers &buf, hipStream_t s, const LaunchTiming &lt, hipStream_t side = nullptr) {

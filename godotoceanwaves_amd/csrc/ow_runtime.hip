@@ -121,6 +121,7 @@ struct ow_context {
         int run_streak = 0;          // how many runs like this one (same delta, same count) have preceded it without anything in between
     } ra;
     bool inside_run = false;    // ow_run is executing (its own ow_update_all calls are not "something in between")
+    int run_frames = 0;         // ... with this many ticks (may_split)
     int pair_dir = 0;           // direction of the next block of the cascade-major pair stream (batches 0 .. B-1 or B-1 .. 0): alternates, across runs too
     bool run_as_calls = false;  // OW_FLAG_RUN_AS_CALLS
     bool run_as_reference = false;  // OW_FLAG_RUN_AS_REFERENCE_SCHEDULE
@@ -179,8 +180,17 @@ static bool side_fork(ow_context *c) {
     return true;
 }
 // every launch of the merged shapes (tick groups, tick pairs): split over the two chains where that pays and the context may
+// On a stream of the CALLER's the second chain has to be joined before every call returns (join_for_caller), and a join -- an event record plus a cross-stream wait --
+// costs 10 - 20 us: more than a split launch gains (4 us at 1024^2 x 4).  So there only the launches of an ow_run of at least 8 ticks (16 at 512^2) are split (one join per
+// run: 1024^2 x 4, K = 10: 51.4 against 52.6 us per tick, K = 5: 53.8 against 53.8; a caller that issues one ow_update_all per tick on its own stream would pay 68 us
+// where one stream takes 51, profiles/r06_chain_region_cost.txt); on the context's own stream nothing is joined until something synchronises, and every launch is split.
+// (512^2 x 8, ticks half as long: K = 10 29.8 against 29.0, K = 20 27.3 against 27.8 -- sixteen ticks there: ~0.4 ms of work either way.)
+static bool may_split(const ow_context *c) {
+    const int min_run = c->n >= 1024 ? 8 : 16;
+    return c->side_stream && (c->own_stream || (c->inside_run && !c->run_as_calls && !c->run_as_reference && c->run_frames >= min_run));
+}
 static hipError_t launch_group(ow_context *c, const ow::FrameArgs &args, const ow::TickGroupArgs &ga, const ow::LaunchTiming &lt = ow::LaunchTiming{}) {
-    if (c->side_stream && !lt.start && ow::tick_pair_splits(c->n, ga) && side_fork(c)) {
+    if (may_split(c) && !lt.start && ow::tick_pair_splits(c->n, ga) && side_fork(c)) {
         ++c->split_launches;
         return ow::launch_tick_group(c->n, args, ga, c->buf, c->stream, lt, c->side_stream);
     }
@@ -1072,8 +1082,8 @@ ow_status ow_create(const ow_config *cfg, ow_context **out) {
             return bail(fail(OW_ERR_HIP, "hipStreamCreate failed"));
         c->own_stream = true;
     }
-    // the second chain's stream (ow_kernels.h "TWO CHAINS"): only where a launch can be split at all -- 1024^2, at least four cascades
-    if (!(cfg->flags & OW_FLAG_SINGLE_STREAM) && c->n == 1024 && c->cascades >= 4) {
+    // the second chain's stream (ow_kernels.h "TWO CHAINS"): only where a launch can be split at all -- 1024^2 with at least four cascades, 512^2 with eight
+    if (!(cfg->flags & OW_FLAG_SINGLE_STREAM) && ((c->n == 1024 && c->cascades >= 4) || (c->n == 512 && c->cascades >= 8))) {
         if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side_fork_ev, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->side_join_ev, hipEventDisableTiming) != hipSuccess)
             return bail(fail(OW_ERR_HIP, "second stream / events: creation failed"));
@@ -1745,8 +1755,10 @@ ow_status ow_run(ow_context *c, double delta, ow_cascade_params *params, int32_t
     const bool follows = ra.last_was_run && ra.last_count == count && std::memcmp(&ra.last_delta, &delta, sizeof(double)) == 0;
     ra.run_streak = follows ? std::min(ra.run_streak + 1, 1 << 20) : 0;
     c->inside_run = true;
+    c->run_frames = frames;
     const ow_status st = run_impl(c, delta, params, count, frames);
     c->inside_run = false;
+    c->run_frames = 0;
     ra.last_was_run = st == OW_OK && frames >= 1;
     ra.last_count = count;
     ra.last_delta = delta;

@@ -132,14 +132,16 @@ typedef struct ow_config {
  * that speculates (one hipMalloc + stream synchronisation inside that call, none afterwards).  For contexts that are only driven through ow_run's
  * tick groups, or many shards on one device; the default keeps every per-frame call free of allocations. */
 #define OW_FLAG_LAZY_SCRATCH 0x2000u
-/* TWO CHAINS (round 6; 1024^2 with four or more cascades).  A tick-pair launch of four 1024^2 cascades on either side is two generations of blocks, and the
- * kernel boundary between two such launches costs a tenth of them (the chip drains and fills again).  Cascades are independent: ow_run and ow_update_all
- * issue such a launch as TWO launches of two cascades each, the second on a stream of the context's own, each half a chain by itself -- one chain's drain
- * runs under the other's body (1024^2 x 4: 52.1 -> 48.0 us per tick on one box; bit-identical maps: the same kernel on the same items).  Everything else
- * the context enqueues or waits for is ordered behind BOTH chains (ow_sync, the readbacks, ow_get_maps, ow_process, ... join first); where the context runs
- * on a stream of the CALLER's (ow_config.stream), the second chain is joined before ow_run / ow_update_all return, so that work the caller enqueues on that
- * stream afterwards finds every map complete, as before.  This flag keeps every launch whole, on the one stream (tests, A/B).  ow_chain_stats: launches
- * that went out as two chains. */
+/* TWO CHAINS (round 6; 1024^2 with four or more cascades, 512^2 with eight).  A tick-pair launch of four 1024^2 (eight 512^2) cascades on either side is two
+ * generations of blocks (one), and the kernel boundary between two such launches costs a tenth of them (the chip drains and fills again).  Cascades are
+ * independent: such a launch goes out as TWO launches of half the cascades each, the second on a stream of the context's own, each half a chain by itself -- one
+ * chain's drain runs under the other's body (1024^2 x 4: 52.1 -> 48.0 us per tick on one box, 512^2 x 8: 27.3 -> 25.6; bit-identical maps: the same kernel on
+ * the same items).  Everything else the context enqueues or waits for is ordered behind BOTH chains (ow_sync, the readbacks, ow_get_maps, ow_process, ... join
+ * first).  Where the context runs on a stream of the CALLER's (ow_config.stream), the second chain is joined before the call returns, so that work the caller
+ * enqueues on that stream afterwards finds every map complete, as before -- and because that join costs more than one split launch gains, on a caller's stream
+ * only the launches of an ow_run of at least 8 ticks (16 at 512^2) are split (one join per run); ow_update_all tick by tick stays on the one stream there.  On the context's
+ * own stream every such launch is split.  This flag keeps every launch whole, on the one stream (tests, A/B).  ow_chain_stats: launches that went out as two
+ * chains. */
 #define OW_FLAG_SINGLE_STREAM 0x4000u
 
 typedef struct ow_context ow_context;

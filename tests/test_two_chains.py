@@ -1,5 +1,5 @@
-"""TWO CHAINS (include/ocean_waves.h, ow_kernels.h; round 6): tick-pair launches of four 1024^2 cascades a side go out as two launches of two cascades
-on two streams, each half a chain of its own.  Same kernel, same items: whatever is called, the maps are BITWISE those of a context whose launches stay
+"""TWO CHAINS (include/ocean_waves.h, ow_kernels.h; round 6): tick-pair launches of four 1024^2 (eight 512^2) cascades a side go out as two launches of
+half the cascades on two streams, each half a chain of its own.  Same kernel, same items: whatever is called, the maps are BITWISE those of a context whose launches stay
 whole on the one stream (OW_FLAG_SINGLE_STREAM), and everything the context enqueues or waits for is ordered behind BOTH chains -- on a stream of the
 caller's the second chain is joined before the call returns."""
 import numpy as np
@@ -31,10 +31,10 @@ def same(a, b, count):
         assert np.array_equal(na.view(np.uint16), nb.view(np.uint16)), i
 
 
-@pytest.mark.parametrize("count", [4, 8])
-def test_two_chains_leave_the_maps_of_one_stream(count):
-    a, pa = make(1024, count, single=False)
-    b, pb = make(1024, count, single=True)
+@pytest.mark.parametrize("n,count", [(1024, 4), (1024, 8), (512, 8)])
+def test_two_chains_leave_the_maps_of_one_stream(n, count):
+    a, pa = make(n, count, single=False)
+    b, pb = make(n, count, single=True)
 
     def both(f):
         f(a, pa); f(b, pb)
@@ -67,9 +67,9 @@ def test_two_chains_leave_the_maps_of_one_stream(count):
     a.free(); b.free()
 
 
-@pytest.mark.parametrize("n,count", [(1024, 2), (1024, 3), (1024, 6), (512, 8), (2048, 1), (256, 4)])
+@pytest.mark.parametrize("n,count", [(1024, 2), (1024, 3), (1024, 6), (512, 7), (512, 4), (2048, 1), (256, 4)])
 def test_nothing_else_is_split(n, count):
-    """a half must still fill the chip and both chains must fit the Infinity Cache: only four 1024^2 cascades a side are split"""
+    """a half must still fill the chip and both chains must fit the Infinity Cache: only four 1024^2 or eight 512^2 cascades a side are split"""
     a, pa = make(n, count, single=False)
     a.run(UPDATE_DELTA, pa, 6); a.run(UPDATE_DELTA, pa, 6)
     for _ in range(4):
@@ -133,3 +133,24 @@ def test_readbacks_and_destruction_with_both_chains_in_flight():
     c.run(UPDATE_DELTA, pc, 3); d.run(UPDATE_DELTA, pd, 3)
     same(c, d, count)
     c.free(); d.free()
+
+
+def test_on_a_callers_stream_only_long_runs_are_split():
+    """every call on a caller's stream ends with the join of the second chain, which costs more than one split launch gains: there only the launches of an
+    ow_run of at least eight ticks are split; on the context's own stream (nothing joins until something synchronises) every such launch is"""
+    import torch
+    n, count = 1024, 4
+    stream = torch.cuda.Stream()
+    gen, pg = make(n, count, single=False, stream=stream.cuda_stream)
+    own, po = make(n, count, single=False)
+    for _ in range(6):
+        gen.update_all(UPDATE_DELTA, pg); own.update_all(UPDATE_DELTA, po)     # (the look-ahead's pair launches from the third call on)
+    assert gen.chain_stats() == 0 and own.chain_stats() > 0
+    gen.run(UPDATE_DELTA, pg, 5); gen.run(UPDATE_DELTA, pg, 7)
+    assert gen.chain_stats() == 0
+    gen.run(UPDATE_DELTA, pg, 8)
+    assert gen.chain_stats() > 0
+    own.run(UPDATE_DELTA, po, 5); own.run(UPDATE_DELTA, po, 7); own.run(UPDATE_DELTA, po, 8)
+    stream.synchronize()
+    same(gen, own, count)       # the same calls, split differently: the same bits
+    gen.free(); own.free()
