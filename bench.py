@@ -61,6 +61,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+SINGLE_STREAM = False  # --single-stream (A/B)
 COPY_CEILING_GBPS = 6290.0  # the same guide's measured copy rate (profiles/r01_membench_copy_ceiling.txt reproduces it)
 # SURVEY.md 8d's contract: algorithmic bytes per texel per cascade-update of a two-pass transform with a four-layer FP32
 # intermediate -- pass 1 reads h0 (16) and writes the intermediate (32); pass 2 reads it (32), reads the previous normal
@@ -101,6 +102,7 @@ def parse():
                                                      "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (numbers are meaningless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="A/B: every context with OW_FLAG_SINGLE_STREAM (the tick-pair launches stay whole, on the one stream: no two chains)")
     ap.add_argument("--no-unmerged", action="store_true", help="time ow_run's regions only: no roofline.unmerged / update_all_calls / reference_schedule beside them")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample size in seconds of host work (runs BEFORE the GPU regions, so that the "
                                                                     "GPU is busy for one contiguous stretch afterwards)")
@@ -396,6 +398,7 @@ def measure_other_config(torch, compute, local_rank, n, C, steps, seconds, senso
     from godotoceanwaves_amd import WaveCascadeParameters, WaveGenerator, cascade_preset, UPDATE_DELTA
     gen = WaveGenerator()
     gen.map_size, gen.device_id, gen.stream = n, local_rank, compute.cuda_stream
+    gen.single_stream = SINGLE_STREAM
     gen.init_gpu(max(2, C))
     drv = Driver(gen, [WaveCascadeParameters(**cascade_preset(i)) for i in range(C)])
     try:
@@ -464,6 +467,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
         g = WaveGenerator()
         g.map_size, g.device_id, g.stream = n, local_rank, compute.cuda_stream
         g.external_maps = (disp.data_ptr(), norm.data_ptr())
+        g.single_stream = SINGLE_STREAM
         for k, v in attrs.items():
             setattr(g, k, v)
         g.init_gpu(layers)
@@ -882,7 +886,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
                              "value_is": "the median region of ow_run over all its blocks"}} if world == 1 else {}),
         "config": {"workload": f"{n}^2 x {C} cascades per GPU, steady-state tick (modulate + 2-D IFFT + unpack/foam), "
                                f"delta=1/50 s, SURVEY 8d cascade table",
-                   "map_size": n, "cascades_per_gpu": C, "parallelism": f"cascade-sharded x{world}",
+                   "map_size": n, "cascades_per_gpu": C, **({"single_stream": True} if SINGLE_STREAM else {}), "parallelism": f"cascade-sharded x{world}",
                    "launches": (f"tick groups: pass 2 of {group_depth} ticks and pass 1 of the next {group_depth} in one launch (k_tick_group_c_lp)"
                                 if launch_mode == "tick_groups_compact" else
                                 "tick pairs: pass 2 of one batch and pass 1 of the next in one launch (k_tick_pair_c)" +
@@ -992,7 +996,9 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
 
 
 def main():
+    global SINGLE_STREAM
     args = parse()
+    SINGLE_STREAM = bool(args.single_stream)
     import torch
     import torch.distributed as dist
 
