@@ -4,7 +4,7 @@ ow_update_all / ow_process) and a context that never merges anything (OW_FLAG_NO
 calls -- update_all with repeating and changing deltas, update + some or all of its process calls (leftovers flushed by the next update),
 runs of a few ticks, live edits (tile length: dirty; whitecap: not), fewer cascades, a restored foam plane, readbacks in between -- and must
 hold the same bits in every map at every check and at the end.
-    python scripts/fuzz_schedule.py [schedules per configuration [first seed]]"""
+    python scripts/fuzz_schedule.py [schedules per configuration [first seed]] [--caller-stream]"""
 import os
 import random
 import sys
@@ -21,14 +21,36 @@ CONFIGS = [(256, 4), (256, 1), (512, 2), (512, 8), (1024, 1), (1024, 3), (256, 8
 DELTAS = (UPDATE_DELTA, UPDATE_DELTA, UPDATE_DELTA, UPDATE_DELTA, 0.03, 1.0 / 60.0)
 
 
+CALLER_STREAM = False   # --caller-stream: the merging context runs on a stream and map arrays of the CALLER's (torch's), and the maps are read by work enqueued on that
+                        # stream with NO synchronising call of the library in between -- the ordering a second chain must be joined for before every call returns
+
+
 def make(n, count, merge):
     gen = WaveGenerator()
     gen.map_size, gen.tick_groups = n, merge
+    if merge and CALLER_STREAM:
+        import torch
+        layers = max(2, count)
+        gen._st = torch.cuda.Stream()
+        gen._disp = torch.zeros((layers, n, n, 4), dtype=torch.float16, device="cuda")
+        gen._norm = torch.zeros_like(gen._disp)
+        torch.cuda.synchronize()
+        gen.stream, gen.external_maps = gen._st.cuda_stream, (gen._disp.data_ptr(), gen._norm.data_ptr())
     gen.init_gpu(max(2, count))
     return gen, [WaveCascadeParameters(**cascade_preset(i)) for i in range(count)]
 
 
 def compare(a, b, count, where):
+    if hasattr(a, "_st"):
+        import torch
+        with torch.cuda.stream(a._st):          # ordered behind the library's work by the caller's stream alone
+            d_dev, n_dev = a._disp.clone(), a._norm.clone()
+        a._st.synchronize(); b.sync()
+        for i in range(count):
+            db, nb = b.get_maps(i)
+            if not (np.array_equal(d_dev[i].cpu().numpy().view(np.uint16), db.view(np.uint16)) and np.array_equal(n_dev[i].cpu().numpy().view(np.uint16), nb.view(np.uint16))):
+                raise AssertionError(f"maps of cascade {i} differ {where} (read on the caller's stream)")
+        return
     a.sync(); b.sync()
     for i in range(count):
         da, na = a.get_maps(i)
@@ -115,6 +137,9 @@ def schedule(n, count, seed, ops=60):
 
 
 if __name__ == "__main__":
+    if "--caller-stream" in sys.argv:
+        sys.argv.remove("--caller-stream")
+        CALLER_STREAM = True
     per_config = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     total = served = 0

@@ -53,6 +53,7 @@ fi
 if want fuzz; then
 timeout 900 python scripts/fuzz_parity.py 30 501 > $O/fuzz.txt 2>&1; tail -3 $O/fuzz.txt
 timeout 900 python scripts/fuzz_schedule.py 12 501 > $O/fuzz_schedule.txt 2>&1; tail -3 $O/fuzz_schedule.txt
+timeout 900 python scripts/fuzz_schedule.py 6 321 --caller-stream > $O/fuzz_schedule_caller_stream.txt 2>&1; tail -1 $O/fuzz_schedule_caller_stream.txt
 fi
 if want margins; then
 timeout 900 python scripts/parity_margins.py > $O/parity_margins.txt 2>&1; grep "^==" $O/parity_margins.txt
