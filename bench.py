@@ -531,7 +531,11 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
     others = {}
     other_errors = {}
     if world == 1 and not args.no_unmerged:
-        for name, attrs in (("update_all_calls", {"run_as_calls": True}), ("unmerged", {"tick_groups": False}), ("reference_schedule", {"run_as_reference": True})):
+        ways = [("update_all_calls", {"run_as_calls": True}), ("unmerged", {"tick_groups": False}), ("reference_schedule", {"run_as_reference": True})]
+        if not SINGLE_STREAM and ((n == 1024 and C in (4, 8)) or (n == 512 and C == 8)):
+            # same-lease A/B of round 6's launch shape: the same ow_run regions with every tick-pair launch whole, on the one stream (OW_FLAG_SINGLE_STREAM)
+            ways.append(("one_stream", {"single_stream": True}))
+        for name, attrs in ways:
             try:  # secondary figures: whatever goes wrong here must not cost the headline line
                 d = make_driver(**attrs)
                 d.update_all(UPDATE_DELTA)
@@ -709,7 +713,7 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
 
     # ---- the other ways' figures (N = 1) ----
     ticks = state["ticks"]               # ticks per timed region (K, or R x K: see regions_per_sync)
-    unmerged = unmerged_samples = calls = calls_hits = None
+    unmerged = unmerged_samples = calls = calls_hits = one_stream = None
     refsched = {}
     for nm, d in others.items():
         smp = samples_of[nm]
@@ -718,6 +722,8 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             unmerged, unmerged_samples = statistics.median(smp), smp
         elif nm == "update_all_calls":
             calls, calls_hits = statistics.median(smp), hit_rate
+        elif nm == "one_stream":
+            one_stream = statistics.median(smp)
         else:
             refsched = {"seconds": statistics.median(smp), "hit_rate": hit_rate}
     unmerged_error, calls_error = other_errors.get("unmerged"), other_errors.get("update_all_calls")
@@ -906,6 +912,9 @@ def measure(args, torch, dist, world, rank, local_rank, n, C, sensors):
             **(grid_scalars(other_configs, round(achieved / HBM_PEAK_GBPS, 4)) if other_configs is not None else {}),
             **({"scene_schedule": scene} if scene is not None else {}),
             **({"clocks": clocks} if clocks is not None else {}),
+            **({"one_stream": {"ms_per_step": round(one_stream / ticks * 1e3, 5), "value": round(maps / one_stream, 2), "unit": "maps/s", "frac": frac_of(one_stream),
+                               "launches": "ow_run as in `value`, every tick-pair launch whole on the one stream (OW_FLAG_SINGLE_STREAM): the same-lease A/B of the two chains"}}
+               if one_stream is not None else ({"one_stream": {"error": other_errors["one_stream"]}} if "one_stream" in other_errors else {})),
             **({"update_all_calls": {"ms_per_step": round(calls / ticks * 1e3, 5), "value": round(maps / calls, 2), "unit": "maps/s",
                                      "lookahead_hit_rate": round(calls_hits, 4), "frac": frac_of(calls),
                                      "launches": "one ow_update_all per tick (OW_FLAG_RUN_AS_CALLS), its adaptive look-ahead on"}}

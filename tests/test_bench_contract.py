@@ -51,6 +51,10 @@ def test_one_json_line_with_the_contract_keys(flags, kernel):
     # ... and the tick-by-tick caller of ow_update_all (one call per tick, its adaptive look-ahead on): between the two
     uc = rf["update_all_calls"]
     assert uc["lookahead_hit_rate"] > 0.9 and 0.0 < uc["frac"] < 0.85 and uc["ms_per_step"] <= 1.05 * um["ms_per_step"]
+    if not flags:  # round 6: the headline's tick-pair launches go out as two chains, and the same regions on ONE stream are timed beside them (same lease): never faster
+        assert rf.get("concurrent_launches") == 2 and rf["one_stream"]["ms_per_step"] >= 0.99 * d["ms_per_step"] and 0.0 < rf["one_stream"]["frac"] <= rf["frac"] + 0.01
+    else:
+        assert "one_stream" not in rf and "concurrent_launches" not in rf
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     rs = d["cpu_baseline"]["reference_shaders"]   # the reference's own GLSL on one host core (oracle/_ref, prebuilt): a bounded sample beside the port
     assert "error" in rs or (rs["kind"] == "reference" and rs["cores"] == 1 and 0.0 < rs["value"] < d["cpu_baseline"]["value"])
