@@ -13,9 +13,11 @@ ap.add_argument("--map-size", type=int, default=1024)
 ap.add_argument("--cascades", type=int, default=4)
 ap.add_argument("--frames", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--single-stream", action="store_true", help="OW_FLAG_SINGLE_STREAM: every tick-pair launch whole, on the one stream (per-launch counters of the whole launch)")
 a = ap.parse_args()
 gen = WaveGenerator()
 gen.map_size = a.map_size
+gen.single_stream = a.single_stream
 gen.init_gpu(max(2, a.cascades))
 params = [WaveCascadeParameters(**cascade_preset(i)) for i in range(a.cascades)]
 gen.run(UPDATE_DELTA, params, a.warmup)
